@@ -1,0 +1,172 @@
+/* vmf_hip.h -- C ABI of libvmf_hip.so: the MI355X (gfx950) implementation of the von Mises-Fisher
+ * latent-sampling path of KHOUTAIBI/MedicalImageAnalysis.
+ *
+ * The reference is pure Python; the binding a maintainer adds is a ctypes stub in each of
+ * sampler/von_mises_fisher.py, sampler/ive.py, sampler/spherical_uniform.py, model/spherical_vae.py,
+ * model/torus_vae.py (shown in INTEGRATION.md).  Every entry point below names the reference lines whose
+ * arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer on the current HIP device unless marked "host";
+ *   - the library never allocates, frees or keeps device memory: outputs and workspaces belong to the caller;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*) and never synchronises;
+ *   - return value: 0 on success, a negative vmf_status otherwise; vmf_last_error_string() describes the
+ *     last failure on the calling thread;
+ *   - dtype selects the arithmetic AND storage type of every floating-point buffer of the call
+ *     (VMF_F32 or VMF_F64), except where a parameter is declared double*;
+ *   - tensors are dense row-major.
+ *   - counter-based noise: Philox4x32-10 with key {seed_lo, seed_hi ^ offset_hi} and counter
+ *     {index_lo, index_hi, slot, offset_lo}; `index` is the GLOBAL row / element index, so a batch sharded
+ *     by rows over several GPUs draws the same numbers as the unsharded batch.
+ */
+#ifndef VMF_HIP_H
+#define VMF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMF_HIP_VERSION 100
+
+typedef void* vmf_stream_t; /* hipStream_t */
+
+enum vmf_status {
+  VMF_OK = 0,
+  VMF_ERR_BAD_ARG = -1,     /* null pointer, negative size, inconsistent shapes */
+  VMF_ERR_DTYPE = -2,       /* dtype is neither VMF_F32 nor VMF_F64 */
+  VMF_ERR_LAUNCH = -3,      /* hipGetLastError() after the launch was not hipSuccess */
+  VMF_ERR_UNSUPPORTED = -4  /* valid request this build has no kernel for (e.g. m > 2048) */
+};
+
+enum vmf_dtype { VMF_F32 = 0, VMF_F64 = 1 };
+
+enum vmf_kl_variant {
+  VMF_KL_SPHERICAL_PIECEWISE = 0, /* model/spherical_vae.py:141-184 (clamp, <1e-3 -> 0, >20 asymptote) */
+  VMF_KL_TORUS_RAW = 1,           /* model/torus_vae.py:190-194 (unguarded sinh/cosh) */
+  VMF_KL_CIRCULAR_EPS = 2,        /* CNN_experiment/circular_VAE.py:126-129 (sinh + 1e-6) */
+  VMF_KL_S1_I0I1 = 3,             /* regular_cnn/s1_vae.py:83-88 (k I1/I0 - log I0, unscaled Bessel) */
+  VMF_KL_STABLE_M3 = 4,           /* same quantity as 0-2 without overflow (no reference counterpart) */
+  VMF_KL_STABLE_M2 = 5            /* same quantity as 3 without overflow (no reference counterpart) */
+};
+
+int vmf_version(void);
+const char* vmf_last_error_string(void);
+
+/* ---- VonMisesFisher3D ------------------------------------------------------------------------
+ * Broadcast description shared by the two calls below.  The result of rsample has `ndim` leading dims
+ * odims[] (then the trailing 3).  Output row o (row-major over odims) reads
+ *     u / w   at element  sum_d idx_d * w_str[d]      (tensor of shape sample_shape + scale.shape)
+ *     scale   at element  sum_d idx_d * k_str[d]
+ *     loc     at row      sum_d idx_d * l_str[d]
+ *     eps     at row      sum_d idx_d * e_str[d]      (tensor of shape sample_shape + loc.shape)
+ * with stride 0 on broadcast dims.  odims and the four stride arrays are HOST arrays of length ndim
+ * (1 <= ndim <= 8). */
+
+/* Replaces VonMisesFisher3D.__init__'s normalisation and .rsample (sampler/von_mises_fisher.py:30, 50-86):
+ *   l = loc/(||loc||+1e-5);  w = 1 + logsumexp(log u, log(1-u) - 2k)/k;  v = normalise(eps - <eps,l> l);
+ *   z = w l + sqrt(clamp(1-w^2, 1e-10, 1)) v.
+ * u / eps may be null: then u[i] comes from Philox(index i, slot 0) and eps row j from Philox(index j,
+ * slot 1) (Box-Muller).  w_out (nullable) receives w, indexed like u. */
+int vmf3_rsample_fwd(const void* loc, const void* scale, const void* u, const void* eps, void* z, void* w_out,
+                     int ndim, const int64_t* odims, const int64_t* w_str, const int64_t* k_str,
+                     const int64_t* l_str, const int64_t* e_str, int dtype, uint64_t seed, uint64_t offset,
+                     vmf_stream_t stream);
+
+/* Backward of the above (what autograd derives from sampler/von_mises_fisher.py:30, 58-84):
+ * dloc (n_loc rows of 3) and dscale (n_scale) receive J^T grad_z.  They are overwritten.  When several
+ * output rows share a loc row or a scale element the partial results are combined with float atomics. */
+int vmf3_rsample_bwd(const void* loc, const void* scale, const void* u, const void* eps, const void* grad_z,
+                     void* dloc, void* dscale, int64_t n_loc, int64_t n_scale, int ndim, const int64_t* odims,
+                     const int64_t* w_str, const int64_t* k_str, const int64_t* l_str, const int64_t* e_str,
+                     int dtype, uint64_t seed, uint64_t offset, vmf_stream_t stream);
+
+/* CNN_experiment/von_mises_fisher.py:88-108 with the reference's sign: logp = k<l,x> - lognorm,
+ * lognorm = log k - log 4pi - log(sinh k + 1e-10).  logp / lognorm nullable. */
+int vmf3_log_prob_ref(const void* loc, const void* scale, const void* x, void* logp, void* lognorm, int64_t n,
+                      int dtype, vmf_stream_t stream);
+
+/* VonMisesFisher3D.mean (sampler/von_mises_fisher.py:38-43): l * ive(3/2,k)/ive(1/2,k) */
+int vmf3_mean(const void* loc, const void* scale, void* mean, int64_t n, int dtype, vmf_stream_t stream);
+
+/* ---- ive --------------------------------------------------------------------------------------
+ * Replaces IveFunction.forward / .backward (sampler/ive.py:12-63), which round-trip through scipy on the
+ * host.  v is the (scalar) order.  Edge conventions follow scipy as the reference sees it: ive(v,0) = [v==0];
+ * negative z: (-1)^v ive(v,|z|) for integer v, NaN otherwise; orders other than 0 and 1 return NaN for
+ * |z| > 2^30 (AMOS's limit).  Regimes: power series / continued fraction (ratio) / uniform asymptotic. */
+int vmf_ive_fwd(double v, const void* z, void* out, int64_t n, int dtype, vmf_stream_t stream);
+/* gz = gout * (ive(v-1,z) - (v/z_safe + sign z) ive(v,z)),  z_safe = (|z|<1e-8 ? 1e-8 : z)   (:54-62) */
+int vmf_ive_bwd(double v, const void* z, const void* gout, void* gz, int64_t n, int dtype, vmf_stream_t stream);
+/* log ive(v,z) for z > 0 without underflow, and I_v(z)/I_{v-1}(z) (no reference counterpart; they feed the
+ * general-m log-normaliser, entropy and KL). */
+int vmf_log_ive_fwd(double v, const void* z, void* out, int64_t n, int dtype, vmf_stream_t stream);
+int vmf_bessel_ratio_fwd(double v, const void* z, void* out, int64_t n, int dtype, vmf_stream_t stream);
+
+/* ---- KL terms ---------------------------------------------------------------------------------
+ * Per-element KL(vMF || uniform) in one of the reference's variants (enum vmf_kl_variant).
+ *   out      nullable: per-element values (what kl_vmf_spherical_uniform returns)
+ *   sum_out  nullable: one double = alpha * sum(out)  (alpha = 1/n gives the `.mean()` of
+ *            model/spherical_vae.py:134); needs `workspace` of at least VMF_KL_WORKSPACE_DOUBLES doubles. */
+#define VMF_KL_WORKSPACE_DOUBLES 1024
+int vmf_kl_fwd(const void* kappa, void* out, double* sum_out, double* workspace, double alpha, int64_t n,
+               int variant, int dtype, vmf_stream_t stream);
+/* dkappa[i] = gout_i * dKL/dkappa(kappa_i); gout is per element (gout_stride = 1) or one scalar
+ * (gout_stride = 0), in the call's dtype; gscale multiplies it (1/n for the fused mean). */
+int vmf_kl_bwd(const void* kappa, const void* gout, int64_t gout_stride, double gscale, void* dkappa, int64_t n,
+               int variant, int dtype, vmf_stream_t stream);
+
+/* ---- general-m von Mises-Fisher (no reference counterpart: the reference asserts m == 3) ----------
+ * Wood (1994) rejection sampler for w with Ulrich's symmetric-Beta proposal, tangent direction from m-1
+ * Gaussians, Householder reflection e1 -> mu:
+ *     b = (m-1)/(2k + sqrt(4k^2+(m-1)^2)), a = ((m-1)+2k+sqrt(4k^2+(m-1)^2))/4, d = 4ab/(1+b) - (m-1)ln(m-1)
+ *     proposal e ~ Beta((m-1)/2,(m-1)/2), u ~ U(0,1): w = (1-(1+b)e)/(1-(1-b)e), t = 2ab/(1-(1-b)e),
+ *     accept iff (m-1) ln t - t + d >= ln u
+ *     z' = [w, sqrt(max(1-w^2,1e-10)) g/||g||],  z = z' - 2<z',h>h/<h,h>,  h = e1 - mu.
+ * mu is (n, m) with row stride mu_stride elements (0: one shared mean), kappa has stride kappa_stride (1 or 0).
+ * Rows are numbered row0 .. row0+n-1 for the noise counters.
+ * Noise: in-kernel Philox by default.  Pre-drawn mode (parity checks): prop_e, prop_u are (n, n_prop)
+ * proposals and gauss is (n, m) normals (column 0 ignored); all three must then be given.
+ * The accepted proposal index (first accepted, or the last one tried when none is) goes to accept_idx.
+ * Outputs w_out (n), omw_out (n; 1 - w computed without cancellation, what the backward wants),
+ * accept_idx (n, int32), logp_out (n; log p(z) fused) are nullable. */
+int vmf_rsample_fwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, void* z, void* w_out,
+                    void* omw_out, int32_t* accept_idx, void* logp_out, int64_t n, int m, const void* prop_e, const void* prop_u,
+                    int n_prop, const void* gauss, int max_prop, uint64_t row0, uint64_t seed, uint64_t offset,
+                    int dtype, vmf_stream_t stream);
+/* Backward through z given the saved w and 1-w (omw; null: 1-w is recomputed from w) -- path-wise through
+ * b(kappa), the accepted proposal held fixed.
+ * gauss null: the Gaussians are regenerated from the same counters.  dmu is (n, m); with mu_stride == 0 or
+ * kappa_stride == 0 the caller reduces dmu / dkappa over rows. */
+int vmf_rsample_bwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, const void* w,
+                    const void* omw, const void* grad_z, const void* gauss, void* dmu, void* dkappa, int64_t n, int m, uint64_t row0,
+                    uint64_t seed, uint64_t offset, int dtype, vmf_stream_t stream);
+/* logp = k<mu,x> + log C_m(k),  log C_m = (m/2-1) log k - (m/2) log 2pi - (log ive(m/2-1,k) + k) */
+int vmf_log_prob_fwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, const void* x,
+                     void* logp, int64_t n, int m, int dtype, vmf_stream_t stream);
+/* gl = dL/dlogp (n): dmu = gl k x, dx = gl k mu, dkappa = gl (<mu,x> - A_m(k)); outputs nullable */
+int vmf_log_prob_bwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, const void* x,
+                     const void* gl, void* dmu, void* dx, void* dkappa, int64_t n, int m, int dtype,
+                     vmf_stream_t stream);
+/* per-row entropy H = -log C_m(k) - k A_m(k), KL(vMF || U(S^{m-1})) = -H + log|S^{m-1}|, and their common
+ * derivative magnitude dKL/dk = -dH/dk = k A_m'(k) (dkl_dk); every output nullable */
+int vmf_entropy_kl_fwd(const void* kappa, void* entropy, void* kl, void* dkl_dk, int64_t n, int m, int dtype,
+                       vmf_stream_t stream);
+
+/* ---- uniform prior and S^1 sampler -----------------------------------------------------------------
+ * SphericalUniform.sample (sampler/spherical_uniform.py:31-33): out = g/||g||, g (n, dim) normals; g null:
+ * Philox(index row0+i, slot 0x20000 + chunk). */
+int vmf_sphere_uniform_sample(const void* gauss, void* out, int64_t n, int dim, uint64_t row0, uint64_t seed,
+                              uint64_t offset, int dtype, vmf_stream_t stream);
+/* S1_VAE.reparameterize (regular_cnn/s1_vae.py:48-55): z = normalize(mean*kappa + noise) with F.normalize's
+ * eps 1e-12; mean/noise/z (n, dim), kappa (n); noise null: Philox as above with slot 0x30000 + chunk. */
+int vmf_s1_projnormal_fwd(const void* mean, const void* kappa, const void* noise, void* z, int64_t n, int dim,
+                          uint64_t row0, uint64_t seed, uint64_t offset, int dtype, vmf_stream_t stream);
+int vmf_s1_projnormal_bwd(const void* mean, const void* kappa, const void* noise, const void* gz, void* dmean,
+                          void* dkappa, int64_t n, int dim, uint64_t row0, uint64_t seed, uint64_t offset, int dtype,
+                          vmf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMF_HIP_H */

@@ -1,0 +1,152 @@
+// bessel_dev.h -- exponentially scaled modified Bessel function I_v on the device (double arithmetic).
+//
+// Three regimes, chosen per element:
+//   power series            v^2 + x^2 <  DEBYE_R2   (x < 30: at most ~80 positive terms)
+//   uniform (Debye) expansion v^2 + x^2 >= DEBYE_R2  (13 terms; truncation error ~1e-15 at the switch)
+//   continued fraction      for the ratio I_v/I_{v-1} in the series region (modified Lentz)
+// The order v is one scalar per launch, so everything that depends on v alone (lgamma) is computed
+// on the host and carried in BesselOrder.
+#pragma once
+#include <math.h>
+
+#include "common.h"
+#include "debye_coeffs.h"
+
+#define VMF_DEBYE_R2 900.0
+#define VMF_AMOS_LIMIT 1073741823.5
+
+struct BesselOrder {
+  double v;            // order as given
+  double av;           // |v| used for the large-x regime
+  double lgam_v1;      // lgamma(v + 1) (for v > -1)
+  double lgam_av1;     // lgamma(|v| + 1)
+  int is_int;          // v is an integer
+  int odd;             // integer and odd
+  int neg_frac;        // -1 < v < 0 (non integer)
+  int unsupported;     // non-integer v <= -1
+  int amos;            // apply AMOS's |z| <= 2^30 limit (scipy.special.ive); 0 for i0e / i1e
+};
+
+static inline BesselOrder make_bessel_order(double v, int amos) {
+  BesselOrder o;
+  o.v = v;
+  o.amos = amos;
+  o.is_int = (v == floor(v));
+  o.neg_frac = (!o.is_int && v < 0 && v > -1.0);
+  o.unsupported = (!o.is_int && v <= -1.0);
+  if (o.is_int && v < 0) v = -v;  // I_{-n} = I_n
+  o.av = fabs(v);
+  o.v = o.is_int ? v : o.v;
+  o.odd = o.is_int && fmod(v, 2.0) != 0.0;
+  o.lgam_v1 = (o.v > -1.0) ? lgamma(o.v + 1.0) : 0.0;
+  o.lgam_av1 = lgamma(o.av + 1.0);
+  return o;
+}
+
+// log of  sum_k (x^2/4)^k / (k! (v+1)_k)
+VMF_HD double bessel_series_logsum(double v, double x) {
+  double q = 0.25 * x * x, term = 1.0, sum = 1.0;
+  for (int k = 1; k < 400; ++k) {
+    term *= q / ((double)k * (v + (double)k));
+    sum += term;
+    if (term < 1e-17 * sum) break;
+  }
+  return ::log(sum);
+}
+
+// log ive(v,x) by the uniform expansion; v >= 0 (for v = 0 it is the Hankel series in 1/x)
+VMF_HD double log_ive_debye(double v, double x) {
+  double r = x > 1e150 ? x : ::sqrt(v * v + x * x);  // x*x would overflow
+  double p = v / r;
+  double rmx = v * v / (r + x);                 // r - x without cancellation
+  double expo = rmx - v * ::log1p((v + rmx) / x);  // v*eta - x
+  double p2 = p * p, pv = 1.0 / r, pk = 1.0, sum = 0.0;  // p/v = 1/r
+#pragma unroll
+  for (int k = 0; k < DEBYE_K; ++k) {
+    double poly = 0.0;
+#pragma unroll
+    for (int j = k; j >= 0; --j) poly = poly * p2 + DEBYE_U[k][j];
+    sum += pk * poly;
+    pk *= pv;
+  }
+  // (2 pi v)^-1/2 (1+z^2)^-1/4 = (2 pi r)^-1/2
+  return expo - 0.5 * ::log(2.0 * M_PI * r) + ::log(sum);
+}
+
+// log ive(v, x), x > 0, v > -1
+VMF_HD double log_ive_pos(double v, double lgam_v1, double x) {
+  if (v * v + x * x < VMF_DEBYE_R2) return v * ::log(0.5 * x) - lgam_v1 - x + bessel_series_logsum(v, x);
+  return log_ive_debye(v, x);
+}
+
+// ive(v, z) with scipy's edge conventions (see include/vmf_hip.h)
+VMF_HD double ive_eval(const BesselOrder& o, double z) {
+  if (z != z) return z;
+  if (o.unsupported) return NAN;
+  double x = z, sign = 1.0, v = o.v;
+  if (x < 0) {
+    if (!o.is_int) return NAN;
+    if (o.odd) sign = -1.0;
+    x = -x;
+  }
+  if (x == 0) return o.is_int ? (v == 0 ? 1.0 : 0.0) : (v < 0 ? NAN : 0.0);
+  if (o.amos && x > VMF_AMOS_LIMIT) return NAN;
+  if (isinf(x)) return 0.0;
+  if (o.neg_frac && x > 20.0) {
+    // I_v = I_{-v} + (2/pi) sin(-v pi) K_{-v}; the K term is < 2 e^{-2x} relative: below one ulp here
+    return ::exp(log_ive_pos(o.av, o.lgam_av1, x));
+  }
+  return sign * ::exp(log_ive_pos(v, o.lgam_v1, x));
+}
+
+// I_v(x)/I_{v-1}(x), v >= 1/2 ... any v with v-1 > -1, x > 0.  lg_v1 = lgamma(v+1), lg_v = lgamma(v).
+VMF_HD double bessel_ratio_eval(double v, double lg_v1, double lg_v, double x) {
+  if (x == 0) return 0.0;
+  if (v * v + x * x < VMF_DEBYE_R2 && (v - 1.0) * (v - 1.0) + x * x < VMF_DEBYE_R2) {
+    // continued fraction  I_v/I_{v-1} = 1/(2v/x + 1/(2(v+1)/x + ...)), modified Lentz
+    const double tiny = 1e-300;
+    double f = tiny, C = f, D = 0.0;
+    for (int k = 0; k < 500; ++k) {
+      double bk = 2.0 * (v + k) / x;
+      D = bk + D;  // a_k = 1
+      if (D == 0.0) D = tiny;
+      C = bk + 1.0 / C;
+      if (C == 0.0) C = tiny;
+      D = 1.0 / D;
+      double delta = C * D;
+      f *= delta;
+      if (::fabs(delta - 1.0) < 1e-16) break;
+    }
+    return f;
+  }
+  return ::exp(log_ive_pos(v, lg_v1, x) - log_ive_pos(v - 1.0, lg_v, x));
+}
+
+// vMF constants that depend on m only (host side)
+struct VmfDim {
+  int m;
+  double v;         // m/2 - 1
+  double lg_v1;     // lgamma(v + 1) = lgamma(m/2)
+  double lg_v2;     // lgamma(v + 2) = lgamma(m/2 + 1)
+  double half_m_log2pi;
+  double log_area;  // log |S^{m-1}| = log 2 + (m/2) log pi - lgamma(m/2)
+};
+static inline VmfDim make_vmf_dim(int m) {
+  VmfDim d;
+  d.m = m;
+  d.v = 0.5 * m - 1.0;
+  d.lg_v1 = lgamma(d.v + 1.0);
+  d.lg_v2 = lgamma(d.v + 2.0);
+  d.half_m_log2pi = 0.5 * m * log(2.0 * M_PI);
+  d.log_area = log(2.0) + 0.5 * m * log(M_PI) - lgamma(0.5 * m);
+  return d;
+}
+
+// log C_m(k) = v log k - (m/2) log 2pi - (log ive(v,k) + k),  v = m/2 - 1
+VMF_HD double vmf_log_norm(const VmfDim& d, double k) {
+  return d.v * ::log(k) - d.half_m_log2pi - (log_ive_pos(d.v, d.lg_v1, k) + k);
+}
+// A_m(k) = I_{m/2}(k) / I_{m/2-1}(k)
+VMF_HD double vmf_mean_resultant(const VmfDim& d, double k) {
+  return bessel_ratio_eval(d.v + 1.0, d.lg_v2, d.lg_v1, k);
+}

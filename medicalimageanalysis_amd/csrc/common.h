@@ -1,0 +1,177 @@
+// common.h -- shared device helpers for libvmf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vmf_hip.h"
+
+// Per-element math is __host__ __device__ so that a host-only check library (tests/) can run the very
+// same functions on the CPU; no product entry point has a CPU path.
+#define VMF_HD __host__ __device__ __forceinline__
+
+// ---- error plumbing -------------------------------------------------------------------------
+void vmf_set_error(const char* fmt, ...);
+int vmf_check_launch(const char* what);
+
+#define VMF_REQUIRE(cond, code, ...)   \
+  do {                                 \
+    if (!(cond)) {                     \
+      vmf_set_error(__VA_ARGS__);      \
+      return (code);                   \
+    }                                  \
+  } while (0)
+
+// Launches `expr` once with T = float or double.
+#define VMF_DISPATCH_DTYPE(dtype, ...)                    \
+  do {                                                    \
+    if ((dtype) == VMF_F32) {                             \
+      using T = float;                                    \
+      __VA_ARGS__;                                        \
+    } else if ((dtype) == VMF_F64) {                      \
+      using T = double;                                   \
+      __VA_ARGS__;                                        \
+    } else {                                              \
+      vmf_set_error("dtype %d is not VMF_F32/VMF_F64", (int)(dtype)); \
+      return VMF_ERR_DTYPE;                               \
+    }                                                     \
+  } while (0)
+
+// Memory-bound elementwise launches: cap the grid and grid-stride the rest.
+static inline int vmf_grid_for(int64_t work_items, int block, int max_blocks = 256 * 8) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  return (int)g;
+}
+
+// ---- Philox4x32-10 --------------------------------------------------------------------------
+struct PhiloxKey {
+  uint32_t k0, k1, c3;  // key words and the 4th counter word (offset_lo)
+};
+static inline PhiloxKey make_philox_key(uint64_t seed, uint64_t offset) {
+  PhiloxKey k;
+  k.k0 = (uint32_t)seed;
+  k.k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32);
+  k.c3 = (uint32_t)offset;
+  return k;
+}
+
+struct U4 {
+  uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ U4 philox4x32_10(uint64_t index, uint32_t slot, PhiloxKey key) {
+  uint32_t c0 = (uint32_t)index, c1 = (uint32_t)(index >> 32), c2 = slot, c3 = key.c3;
+  uint32_t k0 = key.k0, k1 = key.k1;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+
+// 23-bit uniform strictly inside (0,1): ((x >> 9) + 1/2) * 2^-23, exact in fp32 and fp64.
+template <typename T>
+__device__ __forceinline__ T u01(uint32_t x) {
+  return ((T)(x >> 9) + (T)0.5) * (T)(1.0 / 8388608.0);
+}
+
+// ---- type-generic math: accurate (ocml) versions --------------------------------------------
+template <typename T> struct M;
+template <> struct M<float> {
+  static VMF_HD float log(float x) { return ::logf(x); }
+  static VMF_HD float exp(float x) { return ::expf(x); }
+  static VMF_HD float sqrt(float x) { return ::sqrtf(x); }
+  static VMF_HD float sinh(float x) { return ::sinhf(x); }
+  static VMF_HD float cosh(float x) { return ::coshf(x); }
+  static VMF_HD float abs(float x) { return ::fabsf(x); }
+  static VMF_HD float log1p(float x) { return ::log1pf(x); }
+  static VMF_HD float expm1(float x) { return ::expm1f(x); }
+  static __device__ __forceinline__ void sincospi2(float u, float* s, float* c) { ::sincospif(2.0f * u, s, c); }
+};
+template <> struct M<double> {
+  static VMF_HD double log(double x) { return ::log(x); }
+  static VMF_HD double exp(double x) { return ::exp(x); }
+  static VMF_HD double sqrt(double x) { return ::sqrt(x); }
+  static VMF_HD double sinh(double x) { return ::sinh(x); }
+  static VMF_HD double cosh(double x) { return ::cosh(x); }
+  static VMF_HD double abs(double x) { return ::fabs(x); }
+  static VMF_HD double log1p(double x) { return ::log1p(x); }
+  static VMF_HD double expm1(double x) { return ::expm1(x); }
+  static __device__ __forceinline__ void sincospi2(double u, double* s, double* c) { ::sincospi(2.0 * u, s, c); }
+};
+
+// Box-Muller on two uniforms: (sqrt(-2 ln u0) cos 2pi u1, sqrt(-2 ln u0) sin 2pi u1)
+template <typename T>
+__device__ __forceinline__ void box_muller(T u0, T u1, T* n0, T* n1) {
+  T r = M<T>::sqrt((T)-2 * M<T>::log(u0));
+  T s, c;
+  M<T>::sincospi2(u1, &s, &c);
+  *n0 = r * c;
+  *n1 = r * s;
+}
+
+// four normals for elements 4*chunk .. 4*chunk+3 of row `index`
+template <typename T>
+__device__ __forceinline__ void philox_normal4(uint64_t index, uint32_t slot, PhiloxKey key, T out[4]) {
+  U4 r = philox4x32_10(index, slot, key);
+  box_muller<T>(u01<T>(r.x), u01<T>(r.y), &out[0], &out[1]);
+  box_muller<T>(u01<T>(r.z), u01<T>(r.w), &out[2], &out[3]);
+}
+
+// ---- cross-lane: DPP all-reduce inside groups of LPR consecutive lanes --------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f(double x) {
+  long long b = __double_as_longlong(x);
+  int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+constexpr int DPP_QUAD_XOR1 = 0xB1;       // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;       // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+
+// Sum over each aligned group of LPR lanes (LPR a power of two, 1..64); every lane gets the total.
+template <int LPR, typename T>
+__device__ __forceinline__ T group_allreduce_sum(T x) {
+  if (LPR >= 2) x += dpp_f<DPP_QUAD_XOR1>(x);
+  if (LPR >= 4) x += dpp_f<DPP_QUAD_XOR2>(x);
+  if (LPR >= 8) x += dpp_f<DPP_ROW_HALF_MIRROR>(x);
+  if (LPR >= 16) x += dpp_f<DPP_ROW_MIRROR>(x);
+  if (LPR >= 32) x += __shfl_xor(x, 16, 64);
+  if (LPR >= 64) x += __shfl_xor(x, 32, 64);
+  return x;
+}
+
+// block-wide sum in double; result valid in thread 0.  `red` must hold blockDim.x/64 doubles.
+__device__ __forceinline__ double block_sum_double(double x, double* red) {
+  x = group_allreduce_sum<64, double>(x);
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if (lane == 0) red[wave] = x;
+  __syncthreads();
+  double t = 0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+// 16-byte-aligned group of four values (one 128-bit access for float, two for double)
+template <typename T>
+struct alignas(sizeof(T) * 4 > 16 ? 16 : sizeof(T) * 4) Vec4 {
+  T v[4];
+};

@@ -1,0 +1,294 @@
+// elementwise.hip -- ive / log_ive / Bessel ratio, the KL variants with their fused sum, the uniform prior
+// on the sphere and the S^1 projected-normal sampler.  All are streams over kappa / rows: read once, write
+// once, grid capped at 2048 workgroups with a grid-stride loop.
+#include "vmf_math.h"
+
+// ---- ive ---------------------------------------------------------------------------------------------
+// The reference moves z to the host, calls scipy (AMOS / cephes, double internally for either dtype) and
+// copies the result back (sampler/ive.py:18-28).  Here each lane evaluates in double and rounds once to T.
+template <typename T>
+__global__ __launch_bounds__(256) void ive_fwd_kernel(const T* __restrict__ z, T* __restrict__ out, int64_t n,
+                                                      BesselOrder o) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = (T)ive_eval(o, (double)z[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ive_bwd_kernel(const T* __restrict__ z, const T* __restrict__ gout,
+                                                      T* __restrict__ gz, int64_t n, BesselOrder o,
+                                                      BesselOrder om1, T v) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    T zi = z[i];
+    T a = (T)ive_eval(o, (double)zi), b = (T)ive_eval(om1, (double)zi);
+    T zs = M<T>::abs(zi) < (T)1e-8 ? (T)1e-8 : zi;                       // sampler/ive.py:55-56
+    T sg = (T)((zi > (T)0) - (zi < (T)0));                               // torch.sign
+    gz[i] = gout[i] * (b - (v / zs + sg) * a);                           // :60-62
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void log_ive_kernel(const T* __restrict__ z, T* __restrict__ out, int64_t n,
+                                                      double v, double lg_v1) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double x = (double)z[i];
+    out[i] = (T)(x > 0 ? log_ive_pos(v, lg_v1, x) : (x == 0 ? (v == 0 ? 0.0 : -INFINITY) : NAN));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bessel_ratio_kernel(const T* __restrict__ z, T* __restrict__ out,
+                                                           int64_t n, double v, double lg_v1, double lg_v) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double x = (double)z[i];
+    out[i] = (T)(x >= 0 ? bessel_ratio_eval(v, lg_v1, lg_v, x) : NAN);
+  }
+}
+
+extern "C" int vmf_ive_fwd(double v, const void* z, void* out, int64_t n, int dtype, vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(z && out, VMF_ERR_BAD_ARG, "vmf_ive_fwd: null pointer");
+  // forward call site: i0e / i1e for v == 0 / 1, scipy.special.ive otherwise (sampler/ive.py:21-26)
+  BesselOrder o = make_bessel_order(v, !(v == 0.0 || v == 1.0));
+  int grid = vmf_grid_for(n, 256);
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(ive_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                               (const T*)z, (T*)out, n, o));
+  return vmf_check_launch("vmf_ive_fwd");
+}
+
+extern "C" int vmf_ive_bwd(double v, const void* z, const void* gout, void* gz, int64_t n, int dtype,
+                           vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(z && gout && gz, VMF_ERR_BAD_ARG, "vmf_ive_bwd: null pointer");
+  // backward call sites (sampler/ive.py:40-48): v == 0 -> (i0e, ive(-1)); v == 1 -> (i1e, i0e); else ive, ive
+  BesselOrder o = make_bessel_order(v, !(v == 0.0 || v == 1.0));
+  BesselOrder om1 = make_bessel_order(v - 1.0, v != 1.0);
+  int grid = vmf_grid_for(n, 256);
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(ive_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                               (const T*)z, (const T*)gout, (T*)gz, n, o, om1, (T)v));
+  return vmf_check_launch("vmf_ive_bwd");
+}
+
+extern "C" int vmf_log_ive_fwd(double v, const void* z, void* out, int64_t n, int dtype, vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
+  VMF_REQUIRE(v >= 0, VMF_ERR_UNSUPPORTED, "vmf_log_ive_fwd: order %g < 0", v);
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(z && out, VMF_ERR_BAD_ARG, "vmf_log_ive_fwd: null pointer");
+  int grid = vmf_grid_for(n, 256);
+  double lg = lgamma(v + 1.0);
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(log_ive_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                               (const T*)z, (T*)out, n, v, lg));
+  return vmf_check_launch("vmf_log_ive_fwd");
+}
+
+extern "C" int vmf_bessel_ratio_fwd(double v, const void* z, void* out, int64_t n, int dtype,
+                                    vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
+  VMF_REQUIRE(v >= 1.0, VMF_ERR_UNSUPPORTED, "vmf_bessel_ratio_fwd: order %g < 1", v);
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(z && out, VMF_ERR_BAD_ARG, "vmf_bessel_ratio_fwd: null pointer");
+  int grid = vmf_grid_for(n, 256);
+  double lg1 = lgamma(v + 1.0), lg0 = lgamma(v);
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bessel_ratio_kernel<T>, dim3(grid), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)z, (T*)out, n, v, lg1, lg0));
+  return vmf_check_launch("vmf_bessel_ratio_fwd");
+}
+
+// ---- KL ------------------------------------------------------------------------------------------------
+// Replaces the boolean-mask gather/scatter and the two `.any()` host syncs of
+// model/spherical_vae.py:153-182 with one pass; the `.mean()` of :134 is the fused two-stage sum.
+template <typename T>
+__global__ __launch_bounds__(256) void kl_fwd_kernel(const T* __restrict__ kappa, T* __restrict__ out,
+                                                     double* __restrict__ partial, int64_t n, int variant,
+                                                     KlBessel kb) {
+  __shared__ double red[4];
+  double acc = 0;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    T g;
+    T kl = kl_value<T>(kappa[i], variant, kb, &g);
+    if (out) out[i] = kl;
+    acc += (double)kl;
+  }
+  if (partial) {
+    double t = block_sum_double(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void kl_final_kernel(const double* __restrict__ partial, int nblk, double alpha,
+                                                       double* __restrict__ sum_out) {
+  __shared__ double red[4];
+  double acc = 0;
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) acc += partial[i];
+  double t = block_sum_double(acc, red);
+  if (threadIdx.x == 0) *sum_out = alpha * t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void kl_bwd_kernel(const T* __restrict__ kappa, const T* __restrict__ gout,
+                                                     int64_t gstride, T gscale, T* __restrict__ dkappa, int64_t n,
+                                                     int variant, KlBessel kb) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    T g;
+    kl_value<T>(kappa[i], variant, kb, &g);
+    dkappa[i] = gout[i * gstride] * gscale * g;
+  }
+}
+
+extern "C" int vmf_kl_fwd(const void* kappa, void* out, double* sum_out, double* workspace, double alpha,
+                          int64_t n, int variant, int dtype, vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
+  VMF_REQUIRE(variant >= 0 && variant <= VMF_KL_STABLE_M2, VMF_ERR_BAD_ARG, "unknown KL variant %d", variant);
+  VMF_REQUIRE(!sum_out || workspace, VMF_ERR_BAD_ARG, "vmf_kl_fwd: sum_out needs a workspace");
+  VMF_REQUIRE(dtype == VMF_F32 || dtype == VMF_F64, VMF_ERR_DTYPE, "dtype %d", dtype);
+  VMF_REQUIRE(n == 0 || kappa, VMF_ERR_BAD_ARG, "vmf_kl_fwd: null kappa");
+  KlBessel kb = make_kl_bessel();
+  int grid = vmf_grid_for(n, 256, VMF_KL_WORKSPACE_DOUBLES);
+  if (n > 0) {
+    VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(kl_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                                 (const T*)kappa, (T*)out, sum_out ? workspace : nullptr, n,
+                                                 variant, kb));
+    int rc = vmf_check_launch("vmf_kl_fwd");
+    if (rc) return rc;
+  }
+  if (sum_out) {
+    hipLaunchKernelGGL(kl_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, n > 0 ? grid : 0,
+                       alpha, sum_out);
+    return vmf_check_launch("vmf_kl_fwd final");
+  }
+  return VMF_OK;
+}
+
+extern "C" int vmf_kl_bwd(const void* kappa, const void* gout, int64_t gout_stride, double gscale, void* dkappa,
+                          int64_t n, int variant, int dtype, vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
+  VMF_REQUIRE(variant >= 0 && variant <= VMF_KL_STABLE_M2, VMF_ERR_BAD_ARG, "unknown KL variant %d", variant);
+  VMF_REQUIRE(gout_stride == 0 || gout_stride == 1, VMF_ERR_BAD_ARG, "gout_stride must be 0 or 1");
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(kappa && gout && dkappa, VMF_ERR_BAD_ARG, "vmf_kl_bwd: null pointer");
+  KlBessel kb = make_kl_bessel();
+  int grid = vmf_grid_for(n, 256);
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(kl_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                               (const T*)kappa, (const T*)gout, gout_stride, (T)gscale,
+                                               (T*)dkappa, n, variant, kb));
+  return vmf_check_launch("vmf_kl_bwd");
+}
+
+// ---- uniform prior on the sphere / S^1 projected normal ---------------------------------------------------
+// One thread per row; rows here are short (dim 2, 3, 10 in the reference's models).  Counter-based noise is
+// generated twice (norm pass, write pass) instead of being kept in an indexed register array.
+template <typename T>
+__device__ __forceinline__ T row_normal(const T* g, int64_t i, int dim, int c, uint64_t row, uint32_t slot0,
+                                        PhiloxKey key, T cache[4], int* cached_chunk) {
+  if (g) return g[i * dim + c];
+  int ch = c >> 2;
+  if (ch != *cached_chunk) {
+    philox_normal4<T>(row, slot0 + (uint32_t)ch, key, cache);
+    *cached_chunk = ch;
+  }
+  return cache[c & 3];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sphere_uniform_kernel(const T* __restrict__ gauss, T* __restrict__ out,
+                                                             int64_t n, int dim, uint64_t row0, PhiloxKey key) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    T cache[4];
+    int cc = -1;
+    T ss = 0;
+    for (int c = 0; c < dim; ++c) {
+      T g = row_normal<T>(gauss, i, dim, c, row0 + (uint64_t)i, 0x20000u, key, cache, &cc);
+      ss += g * g;
+    }
+    T nn = M<T>::sqrt(ss);  // sampler/spherical_uniform.py:33, no epsilon
+    cc = -1;
+    for (int c = 0; c < dim; ++c)
+      out[i * dim + c] = row_normal<T>(gauss, i, dim, c, row0 + (uint64_t)i, 0x20000u, key, cache, &cc) / nn;
+  }
+}
+
+extern "C" int vmf_sphere_uniform_sample(const void* gauss, void* out, int64_t n, int dim, uint64_t row0,
+                                         uint64_t seed, uint64_t offset, int dtype, vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0 && dim >= 1, VMF_ERR_BAD_ARG, "bad n/dim");
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(out, VMF_ERR_BAD_ARG, "vmf_sphere_uniform_sample: null out");
+  PhiloxKey key = make_philox_key(seed, offset);
+  int grid = vmf_grid_for(n, 256);
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(sphere_uniform_kernel<T>, dim3(grid), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)gauss, (T*)out, n, dim, row0, key));
+  return vmf_check_launch("vmf_sphere_uniform_sample");
+}
+
+// regular_cnn/s1_vae.py:48-55: z = F.normalize(mean*kappa + noise)  (eps 1e-12)
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void s1_projnormal_kernel(const T* __restrict__ mean, const T* __restrict__ kappa,
+                                                            const T* __restrict__ noise, const T* __restrict__ gz,
+                                                            T* __restrict__ z, T* __restrict__ dmean,
+                                                            T* __restrict__ dkappa, int64_t n, int dim,
+                                                            uint64_t row0, PhiloxKey key) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    T cache[4];
+    int cc = -1;
+    T k = kappa[i], ss = 0, yg = 0;
+    for (int c = 0; c < dim; ++c) {
+      T y = mean[i * dim + c] * k + row_normal<T>(noise, i, dim, c, row0 + (uint64_t)i, 0x30000u, key, cache, &cc);
+      ss += y * y;
+      if (BWD) yg += y * gz[i * dim + c];
+    }
+    T nn = M<T>::sqrt(ss);
+    bool clamped = nn < (T)1e-12;
+    if (clamped) nn = (T)1e-12;
+    cc = -1;
+    T dk = 0;
+    for (int c = 0; c < dim; ++c) {
+      T y = mean[i * dim + c] * k + row_normal<T>(noise, i, dim, c, row0 + (uint64_t)i, 0x30000u, key, cache, &cc);
+      if (!BWD) {
+        z[i * dim + c] = y / nn;
+      } else {
+        T dy = clamped ? gz[i * dim + c] / nn : gz[i * dim + c] / nn - y * yg / (nn * nn * nn);
+        dmean[i * dim + c] = k * dy;
+        dk += mean[i * dim + c] * dy;
+      }
+    }
+    if (BWD) dkappa[i] = dk;
+  }
+}
+
+extern "C" int vmf_s1_projnormal_fwd(const void* mean, const void* kappa, const void* noise, void* z, int64_t n,
+                                     int dim, uint64_t row0, uint64_t seed, uint64_t offset, int dtype,
+                                     vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0 && dim >= 1, VMF_ERR_BAD_ARG, "bad n/dim");
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(mean && kappa && z, VMF_ERR_BAD_ARG, "vmf_s1_projnormal_fwd: null pointer");
+  PhiloxKey key = make_philox_key(seed, offset);
+  int grid = vmf_grid_for(n, 256);
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((s1_projnormal_kernel<T, false>), dim3(grid), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)mean, (const T*)kappa,
+                                               (const T*)noise, (const T*)nullptr, (T*)z, (T*)nullptr,
+                                               (T*)nullptr, n, dim, row0, key));
+  return vmf_check_launch("vmf_s1_projnormal_fwd");
+}
+
+extern "C" int vmf_s1_projnormal_bwd(const void* mean, const void* kappa, const void* noise, const void* gz,
+                                     void* dmean, void* dkappa, int64_t n, int dim, uint64_t row0, uint64_t seed,
+                                     uint64_t offset, int dtype, vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0 && dim >= 1, VMF_ERR_BAD_ARG, "bad n/dim");
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(mean && kappa && gz && dmean && dkappa, VMF_ERR_BAD_ARG, "vmf_s1_projnormal_bwd: null pointer");
+  PhiloxKey key = make_philox_key(seed, offset);
+  int grid = vmf_grid_for(n, 256);
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((s1_projnormal_kernel<T, true>), dim3(grid), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)mean, (const T*)kappa,
+                                               (const T*)noise, (const T*)gz, (T*)nullptr, (T*)dmean, (T*)dkappa,
+                                               n, dim, row0, key));
+  return vmf_check_launch("vmf_s1_projnormal_bwd");
+}

@@ -1,0 +1,510 @@
+// vmf_general.hip -- von Mises-Fisher on S^{m-1}, general m: rsample (Wood rejection + Householder),
+// its backward, log_prob, entropy / KL.  gfx950 only.
+//
+// Data layout and work mapping of rsample
+//   mu (n, m) and z (n, m) are dense row-major; a row is split over LPR = min(64, pow2 >= m/4) consecutive
+//   lanes, each lane owning 4 consecutive elements per pass (one 128-bit access in fp32), P passes when
+//   m > 256.  A wave therefore moves 64/LPR rows per step with fully coalesced 1 KiB loads and stores, and
+//   the three row reductions (|g|^2, |e1-mu|^2, <g,mu>) are DPP butterflies inside the LPR-lane group: no
+//   LDS traffic, no atomics.
+//   Each wave owns tiles of TILE_ROWS consecutive rows.  Phase 1 (one row per lane) runs the rejection
+//   sampler for the tile's rows: lanes whose proposal was accepted retire the row (w goes to the wave's LDS
+//   slab) and are refilled with the next unassigned row of the tile through a ballot + prefix popcount, so
+//   the loop trip count follows the tile's MEAN number of proposals, not its maximum.  Phase 2 streams the
+//   rows: load mu, make m-1 normals from Philox in registers, reduce, reflect, store z.
+//   Algorithmic HBM traffic: (2m+1) * sizeof(T) per row (mu in, kappa in, z out); the noise never touches
+//   memory.
+#include "vmf_math.h"
+
+constexpr int TILE_ROWS = 256;
+constexpr int WAVES = 4;
+constexpr uint32_t SLOT_GAUSS = 0x10000u;
+
+template <typename T>
+struct GenParams {
+  const T* mu; int64_t mu_stride;
+  const T* kappa; int64_t kappa_stride;
+  T* z; T* w_out; T* omw_out; int32_t* accept_idx; T* logp;
+  const T* prop_e; const T* prop_u; const T* gauss;
+  int64_t n; int m; int max_prop; uint64_t row0;
+  PhiloxKey key; VmfDim dim;
+  // backward only
+  const T* w_in; const T* omw_in; const T* gz; T* dmu; T* dkappa;
+};
+
+// load the 4 elements [e0, e0+4) of a row (zero beyond m)
+template <typename T, bool VEC>
+__device__ __forceinline__ void load4(const T* __restrict__ rowp, int e0, int m, T out[4]) {
+  if (VEC) {
+    if (e0 < m) {
+      Vec4<T> v = *reinterpret_cast<const Vec4<T>*>(rowp + e0);
+      out[0] = v.v[0]; out[1] = v.v[1]; out[2] = v.v[2]; out[3] = v.v[3];
+    } else {
+      out[0] = out[1] = out[2] = out[3] = (T)0;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = (e0 + i < m) ? rowp[e0 + i] : (T)0;
+  }
+}
+template <typename T, bool VEC>
+__device__ __forceinline__ void store4(T* __restrict__ rowp, int e0, int m, const T in[4]) {
+  if (VEC) {
+    if (e0 < m) {
+      Vec4<T> v;
+      v.v[0] = in[0]; v.v[1] = in[1]; v.v[2] = in[2]; v.v[3] = in[3];
+      *reinterpret_cast<Vec4<T>*>(rowp + e0) = v;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (e0 + i < m) rowp[e0 + i] = in[i];
+  }
+}
+
+// normals for elements [e0, e0+4) of global row `grow`; element 0 and elements >= m are zeroed
+template <typename T, bool VEC>
+__device__ __forceinline__ void noise4(const T* __restrict__ gauss, int64_t row, uint64_t grow, int chunk, int m,
+                                       PhiloxKey key, T g[4]) {
+  int e0 = 4 * chunk;
+  if (gauss) {
+    load4<T, VEC>(gauss + row * (int64_t)m, e0, m, g);
+  } else if (e0 < m) {
+    philox_normal4<T>(grow, SLOT_GAUSS + (uint32_t)chunk, key, g);
+  } else {
+    g[0] = g[1] = g[2] = g[3] = (T)0;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (e0 + i >= m || e0 + i == 0) g[i] = (T)0;
+}
+
+template <typename T, int LPR, int P, bool VEC>
+__global__ __launch_bounds__(WAVES * 64) void vmf_rsample_fwd_kernel(GenParams<T> p) {
+  __shared__ T s_w[WAVES][TILE_ROWS];
+  __shared__ T s_omw[WAVES][TILE_ROWS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int RPI = 64 / LPR;  // rows per wave step
+  const int sub = lane % LPR, grp = lane / LPR;
+  const int m = p.m;
+  const int64_t n_tiles = (p.n + TILE_ROWS - 1) / TILE_ROWS;
+  const int64_t tiles_per_sweep = (int64_t)gridDim.x * WAVES;
+  const int64_t n_sweeps = (n_tiles + tiles_per_sweep - 1) / tiles_per_sweep;  // same for every wave of the grid
+
+  for (int64_t sweep = 0; sweep < n_sweeps; ++sweep) {
+    const int64_t tile = (sweep * gridDim.x + blockIdx.x) * WAVES + wave;
+    const int64_t tile0 = tile * TILE_ROWS;
+    int64_t left = p.n - tile0;
+    const int ntile = left <= 0 ? 0 : (left < TILE_ROWS ? (int)left : TILE_ROWS);
+
+    // ---- phase 1: rejection sampler, one row per lane, accepted lanes refill from the tile's queue ----
+    {
+      int my = lane, next = 64, k = 0;
+      bool active = my < ntile;
+      T a = 0, b = 0, d = 0, kap = 1;
+      if (active) {
+        kap = p.kappa[(tile0 + my) * p.kappa_stride];
+        wood_consts<T>(kap, m, &a, &b, &d);
+      }
+      while (__ballot(active) != 0ull) {
+        bool acc = false;
+        if (active) {
+          const int64_t row = tile0 + my;
+          T e, ua, w, omw;
+          if (p.prop_e) {
+            e = p.prop_e[row * p.max_prop + k];
+            ua = p.prop_u[row * p.max_prop + k];
+          } else {
+            U4 r = philox4x32_10(p.row0 + (uint64_t)row, (uint32_t)k, p.key);
+            e = sym_beta<T>(u01<T>(r.x), u01<T>(r.y), m);
+            ua = u01<T>(r.z);
+          }
+          acc = wood_try<T>(a, b, d, m, e, ua, &w, &omw);
+          if (k + 1 >= p.max_prop) acc = true;  // the last proposal allowed is taken regardless
+          if (acc) {
+            s_w[wave][my] = w;
+            s_omw[wave][my] = omw;
+            if (p.w_out) p.w_out[row] = w;
+            if (p.omw_out) p.omw_out[row] = omw;
+            if (p.accept_idx) p.accept_idx[row] = k;
+          }
+          ++k;
+        }
+        const unsigned long long accm = __ballot(acc);
+        if (acc) {
+          const int rank = __popcll(accm & ((1ull << lane) - 1ull));
+          my = next + rank;
+          k = 0;
+          active = my < ntile;
+          if (active) {
+            kap = p.kappa[(tile0 + my) * p.kappa_stride];
+            wood_consts<T>(kap, m, &a, &b, &d);
+          }
+        }
+        next += __popcll(accm);
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 2: stream the tile's rows, RPI rows per step ----
+    for (int r0 = 0; r0 < ntile; r0 += RPI) {
+      const int r = r0 + grp;
+      const bool valid = r < ntile;
+      const int64_t row = tile0 + (valid ? r : 0);
+      const T* mrow = p.mu + row * p.mu_stride;
+      T mu[P][4], g[P][4];
+      T gg = 0, dd = 0, gm = 0;
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const int chunk = j * LPR + sub;
+        load4<T, VEC>(mrow, 4 * chunk, m, mu[j]);
+        noise4<T, VEC>(p.gauss, row, p.row0 + (uint64_t)row, chunk, m, p.key, g[j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool first = (chunk == 0 && i == 0);
+          const T dmu = first ? (T)1 - mu[j][i] : mu[j][i];
+          gg += g[j][i] * g[j][i];
+          dd += dmu * dmu;
+          gm += g[j][i] * mu[j][i];  // g is zero at element 0
+        }
+      }
+      gg = group_allreduce_sum<LPR, T>(gg);
+      dd = group_allreduce_sum<LPR, T>(dd);
+      gm = group_allreduce_sum<LPR, T>(gm);
+      const T mu0 = __shfl(mu[0][0], lane - sub, 64);
+      const T w = s_w[wave][valid ? r : 0], omw = s_omw[wave][valid ? r : 0];
+      T c2 = omw * ((T)1 + w);
+      c2 = c2 < (T)1e-10 ? (T)1e-10 : c2;
+      const T f = M<T>::sqrt(c2) / M<T>::sqrt(gg);
+      const T d0 = (T)1 - mu0;
+      const T zd = w * d0 - f * gm;
+      const T coef = dd > (T)1e-30 ? (T)2 * zd / dd : (T)0;
+      if (valid) {
+        T* zrow = p.z + row * (int64_t)m;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          const int chunk = j * LPR + sub;
+          T out[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool first = (chunk == 0 && i == 0);
+            out[i] = first ? w - coef * d0 : f * g[j][i] + coef * mu[j][i];
+          }
+          store4<T, VEC>(zrow, 4 * chunk, m, out);
+        }
+        if (p.logp && sub == 0) {
+          const T mm = dd - (T)1 + (T)2 * mu0;                       // |mu|^2
+          const T mz = w * mu0 + f * gm - coef * (mu0 - mm);         // <mu, z>
+          p.logp[row] += p.kappa[row * p.kappa_stride] * mz;  // log C_m(kappa) was stored by the pre-pass
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Backward: one pass over (grad_z, mu) rows; normals regenerated from the counters unless given.
+template <typename T, int LPR, int P, bool VEC>
+__global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T> p) {
+  const int lane = threadIdx.x & 63;
+  constexpr int RPI = 64 / LPR;
+  const int sub = lane % LPR, grp = lane / LPR;
+  const int m = p.m;
+  const int64_t n_steps = (p.n + RPI - 1) / RPI;
+  const int64_t wave_id = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * WAVES;
+  for (int64_t step = wave_id; step < n_steps; step += n_waves) {  // wave-uniform
+    const int64_t r = step * RPI + grp;
+    const bool valid = r < p.n;
+    const int64_t row = valid ? r : 0;
+    const T* mrow = p.mu + row * p.mu_stride;
+    const T* grow_ = p.gz + row * (int64_t)m;
+    T mu[P][4], g[P][4], G[P][4];
+    T gg = 0, dd = 0, gm = 0, Gd = 0, Gg = 0;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const int chunk = j * LPR + sub;
+      load4<T, VEC>(mrow, 4 * chunk, m, mu[j]);
+      load4<T, VEC>(grow_, 4 * chunk, m, G[j]);
+      noise4<T, VEC>(p.gauss, row, p.row0 + (uint64_t)row, chunk, m, p.key, g[j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool first = (chunk == 0 && i == 0);
+        const T de = first ? (T)1 - mu[j][i] : -mu[j][i];
+        gg += g[j][i] * g[j][i];
+        dd += de * de;
+        gm += g[j][i] * mu[j][i];
+        Gd += G[j][i] * de;
+        Gg += G[j][i] * g[j][i];
+      }
+    }
+    gg = group_allreduce_sum<LPR, T>(gg);
+    dd = group_allreduce_sum<LPR, T>(dd);
+    gm = group_allreduce_sum<LPR, T>(gm);
+    Gd = group_allreduce_sum<LPR, T>(Gd);
+    Gg = group_allreduce_sum<LPR, T>(Gg);
+    const T mu0 = __shfl(mu[0][0], lane - sub, 64);
+    const T G0 = __shfl(G[0][0], lane - sub, 64);
+    const T w = p.w_in[row];
+    const T omw = p.omw_in ? p.omw_in[row] : (T)1 - w;
+    const T kap = p.kappa[row * p.kappa_stride];
+    T c2 = omw * ((T)1 + w);
+    const bool inside = c2 >= (T)1e-10;
+    c2 = inside ? c2 : (T)1e-10;
+    const T sq = M<T>::sqrt(c2), gn = M<T>::sqrt(gg);
+    const T f = sq / gn;
+    const T d0 = (T)1 - mu0;
+    const T zd = w * d0 - f * gm;
+    const bool refl = dd > (T)1e-30;
+    const T inv_dd = refl ? (T)1 / dd : (T)0;
+    if (valid) {
+      T* drow = p.dmu + row * (int64_t)m;
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const int chunk = j * LPR + sub;
+        T out[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool first = (chunk == 0 && i == 0);
+          const T zp = first ? w : f * g[j][i];
+          const T de = first ? d0 : -mu[j][i];
+          out[i] = (T)2 * (zp * Gd + zd * G[j][i] - (T)2 * zd * Gd * de * inv_dd) * inv_dd;
+        }
+        store4<T, VEC>(drow, 4 * chunk, m, out);
+      }
+      if (sub == 0) {
+        const T Gp0 = G0 - (T)2 * Gd * inv_dd * d0;
+        const T S = Gg + (T)2 * Gd * gm * inv_dd;
+        const T dw = Gp0 + (inside ? S / gn * (-w / sq) : (T)0);
+        const T m1 = (T)(m - 1);
+        const T c = M<T>::sqrt((T)4 * kap * kap + m1 * m1);
+        const T b = m1 / ((T)2 * kap + c);
+        const T e = omw / (((T)1 + b) - w * ((T)1 - b));
+        const T den = (T)1 - ((T)1 - b) * e;
+        const T dw_db = (T)-2 * e * ((T)1 - e) / (den * den);
+        p.dkappa[row] = dw * dw_db * ((T)-2 * b / c);
+      }
+    }
+  }
+}
+
+// log C_m(kappa_i) for every row: pre-pass of the fused log_prob (keeps the Bessel code, and its registers,
+// out of the streaming kernel)
+template <typename T>
+__global__ __launch_bounds__(256) void vmf_log_norm_kernel(const T* __restrict__ kappa, int64_t kappa_stride,
+                                                           T* __restrict__ out, int64_t n, VmfDim dim) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = (T)vmf_log_norm(dim, (double)kappa[i * kappa_stride]);
+}
+
+// ---- launch plumbing ---------------------------------------------------------------------------------
+template <typename T, int LPR, int P, bool VEC, bool BWD>
+static void launch_one(const GenParams<T>& p, int grid, hipStream_t s) {
+  if (BWD)
+    hipLaunchKernelGGL((vmf_rsample_bwd_kernel<T, LPR, P, VEC>), dim3(grid), dim3(WAVES * 64), 0, s, p);
+  else
+    hipLaunchKernelGGL((vmf_rsample_fwd_kernel<T, LPR, P, VEC>), dim3(grid), dim3(WAVES * 64), 0, s, p);
+}
+
+template <typename T, bool VEC, bool BWD>
+static int launch_shape(const GenParams<T>& p, int grid, hipStream_t s) {
+  const int chunks = (p.m + 3) / 4;
+  if (chunks <= 1) launch_one<T, 1, 1, VEC, BWD>(p, grid, s);
+  else if (chunks <= 2) launch_one<T, 2, 1, VEC, BWD>(p, grid, s);
+  else if (chunks <= 4) launch_one<T, 4, 1, VEC, BWD>(p, grid, s);
+  else if (chunks <= 8) launch_one<T, 8, 1, VEC, BWD>(p, grid, s);
+  else if (chunks <= 16) launch_one<T, 16, 1, VEC, BWD>(p, grid, s);
+  else if (chunks <= 32) launch_one<T, 32, 1, VEC, BWD>(p, grid, s);
+  else if (chunks <= 64) launch_one<T, 64, 1, VEC, BWD>(p, grid, s);
+  else if (chunks <= 128) launch_one<T, 64, 2, VEC, BWD>(p, grid, s);
+  else if (chunks <= 256) launch_one<T, 64, 4, VEC, BWD>(p, grid, s);
+  else if (chunks <= 512) launch_one<T, 64, 8, VEC, BWD>(p, grid, s);
+  else {
+    vmf_set_error("m=%d > 2048 is not supported", p.m);
+    return VMF_ERR_UNSUPPORTED;
+  }
+  return VMF_OK;
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+template <typename T>
+static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, void* z,
+                         void* w_out, void* omw_out, int32_t* accept_idx, void* logp_out, int64_t n, int m,
+                         const void* prop_e, const void* prop_u, int n_prop, const void* gauss, int max_prop,
+                         uint64_t row0, uint64_t seed, uint64_t offset, hipStream_t s) {
+  GenParams<T> p = {};
+  p.mu = (const T*)mu; p.mu_stride = mu_stride; p.kappa = (const T*)kappa; p.kappa_stride = kappa_stride;
+  p.z = (T*)z; p.w_out = (T*)w_out; p.omw_out = (T*)omw_out; p.accept_idx = accept_idx; p.logp = (T*)logp_out;
+  p.prop_e = (const T*)prop_e; p.prop_u = (const T*)prop_u; p.gauss = (const T*)gauss;
+  p.n = n; p.m = m; p.max_prop = prop_e ? n_prop : max_prop; p.row0 = row0;
+  p.key = make_philox_key(seed, offset); p.dim = make_vmf_dim(m);
+  const bool vec = (m % 4 == 0) && (mu_stride % 4 == 0) && aligned16(mu) && aligned16(z) && (!gauss || aligned16(gauss));
+  const int64_t n_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
+  int64_t gb = (n_tiles + WAVES - 1) / WAVES;
+  const int grid = (int)(gb < 1 ? 1 : (gb > 2048 ? 2048 : gb));
+  if (logp_out)
+    hipLaunchKernelGGL(vmf_log_norm_kernel<T>, dim3(vmf_grid_for(n, 256)), dim3(256), 0, s, (const T*)kappa,
+                       kappa_stride, (T*)logp_out, n, p.dim);
+  return vec ? launch_shape<T, true, false>(p, grid, s) : launch_shape<T, false, false>(p, grid, s);
+}
+
+extern "C" int vmf_rsample_fwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, void* z,
+                               void* w_out, void* omw_out, int32_t* accept_idx, void* logp_out, int64_t n, int m,
+                               const void* prop_e, const void* prop_u, int n_prop, const void* gauss, int max_prop,
+                               uint64_t row0, uint64_t seed, uint64_t offset, int dtype, vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
+  VMF_REQUIRE(m >= 2, VMF_ERR_BAD_ARG, "m=%d < 2", m);
+  VMF_REQUIRE(m <= 2048, VMF_ERR_UNSUPPORTED, "m=%d > 2048 is not supported", m);
+  VMF_REQUIRE(mu_stride == 0 || mu_stride >= m, VMF_ERR_BAD_ARG, "mu_stride=%lld", (long long)mu_stride);
+  VMF_REQUIRE(kappa_stride == 0 || kappa_stride == 1, VMF_ERR_BAD_ARG, "kappa_stride must be 0 or 1");
+  const bool pre = prop_e || prop_u || gauss;
+  if (pre) {
+    VMF_REQUIRE(prop_e && prop_u && gauss, VMF_ERR_BAD_ARG, "pre-drawn mode needs prop_e, prop_u and gauss");
+    VMF_REQUIRE(n_prop >= 1, VMF_ERR_BAD_ARG, "n_prop=%d < 1", n_prop);
+  } else {
+    VMF_REQUIRE(max_prop >= 1, VMF_ERR_BAD_ARG, "max_prop=%d < 1", max_prop);
+  }
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(mu && kappa && z, VMF_ERR_BAD_ARG, "vmf_rsample_fwd: null mu/kappa/z");
+  int rc;
+  VMF_DISPATCH_DTYPE(dtype, rc = rsample_fwd_t<T>(mu, mu_stride, kappa, kappa_stride, z, w_out, omw_out, accept_idx,
+                                                  logp_out, n, m, prop_e, prop_u, n_prop, gauss, max_prop, row0,
+                                                  seed, offset, (hipStream_t)stream));
+  if (rc) return rc;
+  return vmf_check_launch("vmf_rsample_fwd");
+}
+
+template <typename T>
+static int rsample_bwd_t(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, const void* w,
+                         const void* omw, const void* gz, const void* gauss, void* dmu, void* dkappa, int64_t n,
+                         int m, uint64_t row0, uint64_t seed, uint64_t offset, hipStream_t s) {
+  GenParams<T> p = {};
+  p.mu = (const T*)mu; p.mu_stride = mu_stride; p.kappa = (const T*)kappa; p.kappa_stride = kappa_stride;
+  p.gauss = (const T*)gauss; p.n = n; p.m = m; p.row0 = row0; p.key = make_philox_key(seed, offset);
+  p.dim = make_vmf_dim(m);
+  p.w_in = (const T*)w; p.omw_in = (const T*)omw; p.gz = (const T*)gz; p.dmu = (T*)dmu; p.dkappa = (T*)dkappa;
+  const bool vec = (m % 4 == 0) && (mu_stride % 4 == 0) && aligned16(mu) && aligned16(gz) && aligned16(dmu) &&
+                   (!gauss || aligned16(gauss));
+  const int chunks = (m + 3) / 4;
+  int lpr = 1;
+  while (lpr < chunks && lpr < 64) lpr *= 2;
+  const int64_t steps = (n + (64 / lpr) - 1) / (64 / lpr);
+  int64_t gb = (steps + WAVES - 1) / WAVES;
+  const int grid = (int)(gb < 1 ? 1 : (gb > 2048 ? 2048 : gb));
+  return vec ? launch_shape<T, true, true>(p, grid, s) : launch_shape<T, false, true>(p, grid, s);
+}
+
+extern "C" int vmf_rsample_bwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride,
+                               const void* w, const void* omw, const void* grad_z, const void* gauss, void* dmu,
+                               void* dkappa, int64_t n, int m, uint64_t row0, uint64_t seed, uint64_t offset,
+                               int dtype, vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
+  VMF_REQUIRE(m >= 2, VMF_ERR_BAD_ARG, "m=%d < 2", m);
+  VMF_REQUIRE(m <= 2048, VMF_ERR_UNSUPPORTED, "m=%d > 2048 is not supported", m);
+  VMF_REQUIRE(mu_stride == 0 || mu_stride >= m, VMF_ERR_BAD_ARG, "mu_stride=%lld", (long long)mu_stride);
+  VMF_REQUIRE(kappa_stride == 0 || kappa_stride == 1, VMF_ERR_BAD_ARG, "kappa_stride must be 0 or 1");
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(mu && kappa && w && grad_z && dmu && dkappa, VMF_ERR_BAD_ARG, "vmf_rsample_bwd: null pointer");
+  int rc;
+  VMF_DISPATCH_DTYPE(dtype, rc = rsample_bwd_t<T>(mu, mu_stride, kappa, kappa_stride, w, omw, grad_z, gauss, dmu,
+                                                  dkappa, n, m, row0, seed, offset, (hipStream_t)stream));
+  if (rc) return rc;
+  return vmf_check_launch("vmf_rsample_bwd");
+}
+
+// ---- log_prob, entropy, KL ----------------------------------------------------------------------------
+// log_prob: a wave takes one row at a time, lanes stride over the row (coalesced), wave reduction.
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void vmf_log_prob_kernel(const T* __restrict__ mu, int64_t mu_stride,
+                                                           const T* __restrict__ kappa, int64_t kappa_stride,
+                                                           const T* __restrict__ x, const T* __restrict__ gl,
+                                                           T* __restrict__ logp, T* __restrict__ dmu,
+                                                           T* __restrict__ dx, T* __restrict__ dkappa, int64_t n,
+                                                           int m, VmfDim dim) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t row = wave_id; row < n; row += n_waves) {
+    const T* mrow = mu + row * mu_stride;
+    const T* xrow = x + row * (int64_t)m;
+    const T k = kappa[row * kappa_stride];
+    T dot = 0;
+    for (int c = lane; c < m; c += 64) dot += mrow[c] * xrow[c];
+    dot = group_allreduce_sum<64, T>(dot);
+    if (!BWD) {
+      if (lane == 0) logp[row] = (T)((double)k * (double)dot + vmf_log_norm(dim, (double)k));
+    } else {
+      const T g = gl[row];
+      for (int c = lane; c < m; c += 64) {
+        if (dmu) dmu[row * (int64_t)m + c] = g * k * xrow[c];
+        if (dx) dx[row * (int64_t)m + c] = g * k * mrow[c];
+      }
+      // d log C_m / dk = -A_m(k)
+      if (dkappa && lane == 0) dkappa[row] = (T)((double)g * ((double)dot - vmf_mean_resultant(dim, (double)k)));
+    }
+  }
+}
+
+extern "C" int vmf_log_prob_fwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride,
+                                const void* x, void* logp, int64_t n, int m, int dtype, vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0 && m >= 2, VMF_ERR_BAD_ARG, "bad n/m");
+  VMF_REQUIRE(kappa_stride == 0 || kappa_stride == 1, VMF_ERR_BAD_ARG, "kappa_stride must be 0 or 1");
+  VMF_REQUIRE(mu_stride == 0 || mu_stride >= m, VMF_ERR_BAD_ARG, "mu_stride=%lld", (long long)mu_stride);
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(mu && kappa && x && logp, VMF_ERR_BAD_ARG, "vmf_log_prob_fwd: null pointer");
+  VmfDim dim = make_vmf_dim(m);
+  int grid = vmf_grid_for(n, 4);
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((vmf_log_prob_kernel<T, false>), dim3(grid), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)mu, mu_stride, (const T*)kappa,
+                                               kappa_stride, (const T*)x, (const T*)nullptr, (T*)logp, (T*)nullptr,
+                                               (T*)nullptr, (T*)nullptr, n, m, dim));
+  return vmf_check_launch("vmf_log_prob_fwd");
+}
+
+extern "C" int vmf_log_prob_bwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride,
+                                const void* x, const void* gl, void* dmu, void* dx, void* dkappa, int64_t n, int m,
+                                int dtype, vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0 && m >= 2, VMF_ERR_BAD_ARG, "bad n/m");
+  VMF_REQUIRE(kappa_stride == 0 || kappa_stride == 1, VMF_ERR_BAD_ARG, "kappa_stride must be 0 or 1");
+  VMF_REQUIRE(mu_stride == 0 || mu_stride >= m, VMF_ERR_BAD_ARG, "mu_stride=%lld", (long long)mu_stride);
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(mu && kappa && x && gl, VMF_ERR_BAD_ARG, "vmf_log_prob_bwd: null pointer");
+  VmfDim dim = make_vmf_dim(m);
+  int grid = vmf_grid_for(n, 4);
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((vmf_log_prob_kernel<T, true>), dim3(grid), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)mu, mu_stride, (const T*)kappa,
+                                               kappa_stride, (const T*)x, (const T*)gl, (T*)nullptr, (T*)dmu,
+                                               (T*)dx, (T*)dkappa, n, m, dim));
+  return vmf_check_launch("vmf_log_prob_bwd");
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vmf_entropy_kl_kernel(const T* __restrict__ kappa, T* __restrict__ entropy,
+                                                             T* __restrict__ kl, T* __restrict__ dkl, int64_t n,
+                                                             VmfDim dim) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double k = (double)kappa[i];
+    const double A = vmf_mean_resultant(dim, k);
+    const double H = -vmf_log_norm(dim, k) - k * A;
+    if (entropy) entropy[i] = (T)H;
+    if (kl) kl[i] = (T)(-H + dim.log_area);
+    // dKL/dk = k A'(k),  A' = 1 - A^2 - (m-1) A / k
+    if (dkl) dkl[i] = (T)(k * (1.0 - A * A) - (double)(dim.m - 1) * A);
+  }
+}
+
+extern "C" int vmf_entropy_kl_fwd(const void* kappa, void* entropy, void* kl, void* dkl_dk, int64_t n, int m,
+                                  int dtype, vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0 && m >= 2, VMF_ERR_BAD_ARG, "bad n/m");
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(kappa, VMF_ERR_BAD_ARG, "vmf_entropy_kl_fwd: null kappa");
+  VmfDim dim = make_vmf_dim(m);
+  int grid = vmf_grid_for(n, 256);
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(vmf_entropy_kl_kernel<T>, dim3(grid), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)kappa, (T*)entropy, (T*)kl,
+                                               (T*)dkl_dk, n, dim));
+  return vmf_check_launch("vmf_entropy_kl_fwd");
+}

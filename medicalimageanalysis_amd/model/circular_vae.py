@@ -1,0 +1,61 @@
+"""Drop-in for the reference's CNN_experiment/circular_VAE.py (kappa squeezed to (B,), so z is (B, 3))."""
+import torch
+import torch.nn as nn
+
+from ..sampler.von_mises_fisher import VonMisesFisher3DLogProb as VonMisesFisher3D
+from .. import kl as _kl
+
+
+class CircularVAE(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.device = config["device"]
+        self.extrinsic_dim = config["extrinsic_dim"]
+        self.encoder_net = nn.Sequential(
+            nn.Softplus(beta=1.0),
+            nn.Linear(self.extrinsic_dim, config["encoder_width"]),
+            nn.Softplus(beta=1.0),
+            nn.Linear(config["encoder_width"], config["encoder_width"]),
+            nn.Softplus(beta=1.0),
+            nn.Linear(config["encoder_width"], config["encoder_width"]),
+        )
+        self.fc_mu = nn.Linear(config["encoder_width"], 3)
+        self.fc_logvar = nn.Linear(config["encoder_width"], 1)
+        self.decoder_net = nn.Sequential(
+            nn.Linear(3, config["decoder_width"]),
+            nn.Softplus(beta=1.0),
+            nn.Linear(config["decoder_width"], config["decoder_width"]),
+            nn.Softplus(beta=1.0),
+            nn.Linear(config["decoder_width"], self.extrinsic_dim),
+        )
+
+    def encode(self, x):
+        h = self.encoder_net(x)
+        mu = self.fc_mu(h)
+        logvar = nn.functional.softplus(self.fc_logvar(h)) + 1
+        return mu, logvar.squeeze(-1)  # CNN_experiment/circular_VAE.py:47-53
+
+    def reparameterize(self, mu, logvar):
+        q_z = VonMisesFisher3D(mu, logvar)
+        return q_z.rsample(), (mu, logvar)  # :74-76
+
+    def decode(self, z):
+        return self.decoder_net(z)
+
+    def forward(self, x):
+        mu, logvar = self.encode(x)
+        z_sample, params = self.reparameterize(mu, logvar)
+        x_recon = self.decode(z_sample)
+        return z_sample, x_recon, (mu, logvar)
+
+    def _elbo(self, x, x_recon, posterior_params):
+        z_mu, z_kappa = posterior_params
+        q_z = VonMisesFisher3D(z_mu, z_kappa)
+        kappa = q_z.scale
+        KL = _kl.kl_mean(kappa, "circular")
+        reconstruction_loss = torch.mean((x - x_recon) * (x - x_recon))
+        return self.config["gamma"] * reconstruction_loss + self.config["beta"] * KL  # :106-116
+
+    def kl_vmf_spherical_uniform(self, kappa) -> torch.Tensor:
+        return _kl.kl_per_sample(kappa, "circular")  # :118-130

@@ -1,0 +1,99 @@
+"""Drop-in for the reference's model/torus_vae.py (same names, including the attribute spellings
+`shortes_radius` and `fucntion_z_phi_logvar`).  geomstats is not needed: `gs.stack` is `torch.stack`."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import numpy as np  # noqa: F401
+
+from ..sampler.spherical_uniform import *  # noqa: F401,F403
+from ..sampler.von_mises_fisher import *  # noqa: F401,F403
+from ..sampler.spherical_uniform import SphericalUniform
+from ..sampler.von_mises_fisher import VonMisesFisher3D
+from .. import kl as _kl
+
+
+class ToroidalVAE(nn.Module):
+    def __init__(self, config, *args, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.config = config
+        self.extrinsic_dim = config["extrinsic_dim"]
+        self.latent_dim = config["latent_dim"]
+        self.sftbeta = config["sftbeta"]
+        self.encoder_width = config["encoder_width"]
+        self.encoder_depth = config["encoder_depth"]
+        self.decoder_width = config["decoder_width"]
+        self.decoder_depth = config["decoder_depth"]
+        self.dropout_p = config["dropout_p"]
+        self.device = config["device"]
+        self.longest_radius = config["longest_radius"]
+        self.shortes_radius = config["shortest_radius"]
+
+        dev = self.device
+        self.encoder_function = nn.Linear(self.extrinsic_dim, self.encoder_width, device=dev)
+        self.encoder_linear_layers = nn.ModuleList(
+            [nn.Linear(self.encoder_width, self.encoder_width, device=dev) for _ in range(self.encoder_depth)])
+        self.function_z_theta_mu = nn.Linear(self.encoder_width, self.latent_dim, device=dev)
+        self.function_z_theta_logvar = nn.Linear(self.encoder_width, 1, device=dev)
+        self.function_z_phi_mu = nn.Linear(self.encoder_width, self.latent_dim, device=dev)
+        self.fucntion_z_phi_logvar = nn.Linear(self.encoder_width, 1, device=dev)
+        self.decoder_function = nn.Linear(self.latent_dim, self.decoder_width, device=dev)
+        self.decoder_linear_layers = nn.ModuleList(
+            [nn.Linear(self.decoder_width, self.decoder_width, device=dev) for _ in range(self.decoder_depth)])
+        self.function_x_mu = nn.Linear(self.decoder_width, self.extrinsic_dim, device=dev)
+        self.dropout = nn.Dropout(p=self.dropout_p)
+
+    def _build_torus(self, z_theta, z_phi):
+        """model/torus_vae.py:60-81: the first two components of each sphere sample act as (cos, sin);
+        y uses (r + r cos theta), as the reference does."""
+        cos_theta, sin_theta = z_theta[..., 0], z_theta[..., 1]
+        cos_phi, sin_phi = z_phi[..., 0], z_phi[..., 1]
+        R, r = self.longest_radius, self.shortes_radius
+        x = (R + r * cos_theta) * cos_phi
+        y = (r + r * cos_theta) * sin_phi
+        z = r * sin_theta
+        return torch.stack([x, y, z], dim=-1)
+
+    def encode(self, x):
+        h = F.softplus(self.encoder_function(x), beta=self.sftbeta)
+        for layer in self.encoder_linear_layers:
+            h = F.softplus(layer(h), beta=self.sftbeta)
+        z_theta_mu = self.function_z_theta_mu(h)
+        z_theta_logvar = F.softplus(self.function_z_theta_logvar(h)) + 1
+        z_phi_mu = self.function_z_phi_mu(h)
+        z_phi_logvar = F.softplus(self.fucntion_z_phi_logvar(h)) + 1
+        return z_theta_mu, z_theta_logvar, z_phi_mu, z_phi_logvar
+
+    def reparemetrize(self, posteriori_params):
+        """two independent draws, theta first then phi (model/torus_vae.py:109-124)"""
+        z_theta_mu, z_theta_kappa, z_phi_mu, z_phi_kappa = posteriori_params
+        q_theta_z = VonMisesFisher3D(z_theta_mu, z_theta_kappa)
+        q_phi_z = VonMisesFisher3D(z_phi_mu, z_phi_kappa)
+        z_theta = q_theta_z.rsample()
+        z_phi = q_phi_z.rsample()
+        return self._build_torus(z_theta, z_phi)
+
+    def decode(self, z):
+        h = F.softplus(self.decoder_function(z), beta=self.sftbeta)
+        for layer in self.decoder_linear_layers:
+            h = F.softplus(layer(h), beta=self.sftbeta)
+        return self.function_x_mu(h)
+
+    def forward(self, x):
+        posteriori_params = self.encode(x)
+        z = self.reparemetrize(posteriori_params)
+        x_mu = self.decode(z)
+        return z, x_mu, posteriori_params
+
+    def _elbo(self, x, x_mu, posteriori_params):
+        """called once per angle pair by the training loop (model/train.py:74-77)"""
+        z_mu, z_kappa = posteriori_params
+        q_z = VonMisesFisher3D(z_mu, z_kappa)
+        p_z = SphericalUniform(dim=self.latent_dim - 1, device=x.device)  # noqa: F841
+        kappa = q_z.scale
+        KL = _kl.kl_mean(kappa, "torus")
+        reconstruction_loss = torch.mean((x - x_mu) * (x - x_mu))
+        return self.config["gamma"] * reconstruction_loss + self.config["beta"] * KL
+
+    def kl_vmf_spherical_uniform(self, kappa) -> torch.Tensor:
+        """unguarded form of model/torus_vae.py:182-194 (NaN once sinh overflows, like the reference)"""
+        return _kl.kl_per_sample(kappa, "torus")

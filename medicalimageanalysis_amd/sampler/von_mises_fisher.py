@@ -1,0 +1,413 @@
+"""Drop-in for the reference's sampler/von_mises_fisher.py (`VonMisesFisher3D`), the variant with `log_prob`
+from CNN_experiment/von_mises_fisher.py (`VonMisesFisher3DLogProb`), and the general-m `VonMisesFisher`
+(Wood rejection sampler + Householder reflection) the reference does not have.
+
+Everything numerical runs in libvmf_hip.so on the tensors' HIP device; this file is shape logic, argument
+checks and autograd glue.
+"""
+import math  # noqa: F401  (re-exported: the reference's model files reach `math` through `from sampler.von_mises_fisher import *`)
+
+import torch
+from torch.distributions import Distribution, constraints
+from torch.distributions.kl import register_kl
+
+from .. import _lib, rng
+from .ive import ive
+from .spherical_uniform import HypersphericalUniform
+
+__all__ = ["math", "torch", "ive", "Distribution", "constraints", "VonMisesFisher3D", "VonMisesFisher3DLogProb",
+           "VonMisesFisher", "HypersphericalUniform"]
+
+_MAX_DIMS = 8
+
+
+# ---- broadcast plan of VonMisesFisher3D.rsample --------------------------------------------------------
+def _bstrides(shape, target):
+    """element strides of a dense tensor of `shape` viewed as broadcast to `target` (0 on broadcast dims)"""
+    nd = len(target)
+    shape = (1,) * (nd - len(shape)) + tuple(shape)
+    st, acc = [0] * nd, 1
+    for d in range(nd - 1, -1, -1):
+        if shape[d] != 1:
+            assert shape[d] == target[d]
+            st[d] = acc
+        acc *= shape[d]
+    return st
+
+
+def vmf3_broadcast_plan(loc_shape, scale_shape, sample_shape=()):
+    """Shapes/strides of `w.unsqueeze(-1) * loc + factor * v` (sampler/von_mises_fisher.py:82-84).
+
+    w has shape sample_shape + scale.shape, loc/eps/v have shape sample_shape + loc.shape; the result is their
+    broadcast -- (B, 3) for scale (B,), and the (B, B, 3) outer product for the (B, 1) scale the VAEs pass."""
+    loc_shape, scale_shape, sample_shape = tuple(loc_shape), tuple(scale_shape), tuple(sample_shape)
+    lrows = loc_shape[:-1]
+    w_shape = sample_shape + scale_shape
+    e_shape = sample_shape + lrows
+    o_shape = tuple(torch.broadcast_shapes(w_shape, e_shape))  # raises RuntimeError like the reference's `*`
+    odims = o_shape if len(o_shape) else (1,)
+    if len(odims) > _MAX_DIMS:
+        raise RuntimeError(f"rsample result has {len(odims)} batch dims; at most {_MAX_DIMS} are supported")
+    pad = lambda s: s if len(o_shape) else [0]  # noqa: E731
+    return {
+        "o_shape": o_shape, "w_shape": w_shape, "e_shape": e_shape, "odims": list(odims),
+        "w_str": pad(_bstrides(w_shape, o_shape)), "k_str": pad(_bstrides(scale_shape, o_shape)),
+        "l_str": pad(_bstrides(lrows, o_shape)), "e_str": pad(_bstrides(e_shape, o_shape)),
+    }
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= int(s)
+    return n
+
+
+class _VMF3RSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, loc, scale, u, eps, plan, seed, offset):
+        dev = _lib.require_hip(loc, scale, u, eps)
+        locc, scalec = loc.detach().contiguous(), scale.detach().contiguous()
+        uc = None if u is None else u.contiguous()
+        epsc = None if eps is None else eps.contiguous()
+        z = torch.empty(plan["o_shape"] + (3,), device=dev, dtype=loc.dtype)
+        if z.numel():
+            with torch.cuda.device(dev):
+                rc = _lib.lib().vmf3_rsample_fwd(
+                    _lib.ptr(locc), _lib.ptr(scalec), _lib.ptr(uc), _lib.ptr(epsc), _lib.ptr(z), None,
+                    len(plan["odims"]), _lib.i64_array(plan["odims"]), _lib.i64_array(plan["w_str"]),
+                    _lib.i64_array(plan["k_str"]), _lib.i64_array(plan["l_str"]), _lib.i64_array(plan["e_str"]),
+                    _lib.dtype_code(loc), seed, offset, _lib.stream_ptr(dev))
+            _lib.check(rc, "vmf3_rsample_fwd")
+        ctx.save_for_backward(locc, scalec, uc, epsc)
+        ctx.plan, ctx.seed, ctx.offset = plan, seed, offset
+        ctx.loc_shape, ctx.scale_shape = loc.shape, scale.shape
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        locc, scalec, uc, epsc = ctx.saved_tensors
+        plan = ctx.plan
+        dev = locc.device
+        gzc = gz.to(locc.dtype).contiguous()
+        dloc, dscale = torch.empty_like(locc), torch.empty_like(scalec)
+        if dloc.numel() or dscale.numel():
+            with torch.cuda.device(dev):
+                rc = _lib.lib().vmf3_rsample_bwd(
+                    _lib.ptr(locc), _lib.ptr(scalec), _lib.ptr(uc), _lib.ptr(epsc), _lib.ptr(gzc), _lib.ptr(dloc),
+                    _lib.ptr(dscale), locc.numel() // 3, scalec.numel(), len(plan["odims"]),
+                    _lib.i64_array(plan["odims"]), _lib.i64_array(plan["w_str"]), _lib.i64_array(plan["k_str"]),
+                    _lib.i64_array(plan["l_str"]), _lib.i64_array(plan["e_str"]), _lib.dtype_code(locc), ctx.seed,
+                    ctx.offset, _lib.stream_ptr(dev))
+            _lib.check(rc, "vmf3_rsample_bwd")
+        return dloc.view(ctx.loc_shape), dscale.view(ctx.scale_shape), None, None, None, None, None
+
+
+class VonMisesFisher3D(Distribution):
+    """
+    Simpler von Mises-Fisher distribution on the unit sphere in R^3 (sampler/von_mises_fisher.py:7-86).
+
+    Parameters
+    ----------
+    loc : tensor (..., 3)
+        Mean direction; normalised as loc / (||loc|| + 1e-5) like the reference (:30).
+    scale : tensor (...) -- or (..., 1), which broadcasts rsample() to (B, B, 3) exactly as the reference does.
+        Concentration kappa > 0.
+    """
+
+    arg_constraints = {
+        "loc": constraints.real,
+        "scale": constraints.positive,
+    }  # type: ignore
+    support = constraints.real  # type: ignore
+    has_rsample = True
+
+    def __init__(self, loc, scale, validate_args=None):
+        assert loc.shape[-1] == 3, "This simple version o"
+        self._loc_raw = loc
+        self._loc_n = None
+        self.scale = scale
+        self.device = loc.device
+        self.dtype = loc.dtype
+        super().__init__(batch_shape=loc.shape[:-1], validate_args=validate_args)
+
+    @property
+    def loc(self):
+        """loc / (||loc|| + 1e-5)  (:30).  The kernels normalise the raw loc themselves, so this tensor is only
+        built when somebody reads it (argument validation, mean())."""
+        if self._loc_n is None:
+            self._loc_n = self._loc_raw / (self._loc_raw.norm(dim=-1, keepdim=True) + 1e-5)
+        return self._loc_n
+
+    def mean(self):
+        # E[X] = A_m(kappa) * mu with m=3  (:38-43); a method, as in the reference
+        m = 3
+        kappa = self.scale
+        A = ive(m / 2, kappa) / ive(m / 2 - 1, kappa)  # type: ignore
+        return self.loc * A.unsqueeze(-1)
+
+    def stddev(self):
+        return self.scale  # (:46-48)
+
+    def rsample(self, sample_shape=torch.Size()):
+        """Reparameterised sample of shape broadcast(sample_shape + scale.shape, sample_shape + batch_shape) + (3,)
+        (:66-86).  Noise: VMF_RNG=torch (default) draws u then eps from torch's generator in the reference's
+        order; VMF_RNG=philox generates both inside the kernel."""
+        sample_shape = torch.Size(sample_shape)
+        loc = self._loc_raw
+        scale = self.scale if self.scale.dtype == loc.dtype else self.scale.to(loc.dtype)
+        _lib.require_hip(loc, scale)
+        plan = vmf3_broadcast_plan(loc.shape, scale.shape, sample_shape)
+        if rng.rng_mode() == "torch":
+            u = torch.rand(plan["w_shape"], device=self.device, dtype=self.dtype)         # :56
+            eps = torch.randn(plan["e_shape"] + (3,), device=self.device, dtype=self.dtype)  # :75
+            seed = offset = 0
+        else:
+            u = eps = None
+            seed, offset = rng.default_generator.next_offset()
+        return _VMF3RSample.apply(loc, scale, u, eps, plan, seed, offset)
+
+    def rsample_with_noise(self, u, eps, sample_shape=torch.Size()):
+        """rsample with the caller's noise: u of shape sample_shape + scale.shape (uniform), eps of shape
+        sample_shape + loc.shape (normal).  This is what the parity tests drive."""
+        sample_shape = torch.Size(sample_shape)
+        loc = self._loc_raw
+        scale = self.scale if self.scale.dtype == loc.dtype else self.scale.to(loc.dtype)
+        plan = vmf3_broadcast_plan(loc.shape, scale.shape, sample_shape)
+        if tuple(u.shape) != plan["w_shape"] or tuple(eps.shape) != plan["e_shape"] + (3,):
+            raise ValueError(f"noise shapes {tuple(u.shape)}, {tuple(eps.shape)} do not match "
+                             f"{plan['w_shape']}, {plan['e_shape'] + (3,)}")
+        return _VMF3RSample.apply(loc, scale, u.to(loc.dtype), eps.to(loc.dtype), plan, 0, 0)
+
+    def mean_fused(self):
+        """mean() in one kernel (no autograd): loc_n * ive(3/2, k) / ive(1/2, k)."""
+        loc = self._loc_raw.detach().contiguous()
+        scale = self.scale.detach().to(loc.dtype).expand(loc.shape[:-1]).contiguous()
+        dev = _lib.require_hip(loc, scale)
+        out = torch.empty_like(loc)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().vmf3_mean(_lib.ptr(loc), _lib.ptr(scale), _lib.ptr(out), scale.numel(),
+                                      _lib.dtype_code(loc), _lib.stream_ptr(dev))
+        _lib.check(rc, "vmf3_mean")
+        return out
+
+
+class VonMisesFisher3DLogProb(VonMisesFisher3D):
+    """The copy in CNN_experiment/von_mises_fisher.py, which adds log_prob / _log_normalization (:88-108) with the
+    reference's sign convention: log_prob = kappa <loc, x> - (log kappa - log 4 pi - log(sinh kappa + 1e-10))."""
+
+    def _launch(self, x):
+        loc = self._loc_raw.detach()
+        bshape = torch.broadcast_shapes(loc.shape[:-1], self.scale.shape, x.shape[:-1] if x is not None else ())
+        locb = loc.expand(bshape + (3,)).contiguous()
+        scaleb = self.scale.detach().to(loc.dtype).expand(bshape).contiguous()
+        xb = None if x is None else x.detach().to(loc.dtype).expand(bshape + (3,)).contiguous()
+        dev = _lib.require_hip(locb, scaleb, xb)
+        logp = None if x is None else torch.empty(bshape, device=dev, dtype=loc.dtype)
+        lognorm = torch.empty(bshape, device=dev, dtype=loc.dtype) if x is None else None
+        with torch.cuda.device(dev):
+            rc = _lib.lib().vmf3_log_prob_ref(_lib.ptr(locb), _lib.ptr(scaleb), _lib.ptr(xb), _lib.ptr(logp),
+                                              _lib.ptr(lognorm), scaleb.numel(), _lib.dtype_code(locb),
+                                              _lib.stream_ptr(dev))
+        _lib.check(rc, "vmf3_log_prob_ref")
+        return logp if x is not None else lognorm
+
+    def log_prob(self, x):
+        return self._launch(x)
+
+    def _log_normalization(self):
+        return self._launch(None)
+
+
+# ---- general m ---------------------------------------------------------------------------------------------
+class _VMFRSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, kappa, n, mu_stride, kappa_stride, max_prop, row0, seed, offset, want_logp):
+        dev = _lib.require_hip(mu, kappa)
+        m = mu.shape[-1]
+        muc, kc = mu.detach().contiguous(), kappa.detach().contiguous()
+        z = torch.empty((n, m), device=dev, dtype=mu.dtype)
+        w = torch.empty((n,), device=dev, dtype=mu.dtype)
+        omw = torch.empty((n,), device=dev, dtype=mu.dtype)
+        logp = torch.empty((n,), device=dev, dtype=mu.dtype) if want_logp else None
+        with torch.cuda.device(dev):
+            rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(muc), mu_stride, _lib.ptr(kc), kappa_stride, _lib.ptr(z),
+                                            _lib.ptr(w), _lib.ptr(omw), None, _lib.ptr(logp), n, m, None, None, 0,
+                                            None, max_prop, row0, seed, offset, _lib.dtype_code(muc),
+                                            _lib.stream_ptr(dev))
+        _lib.check(rc, "vmf_rsample_fwd")
+        ctx.save_for_backward(muc, kc, w, omw)
+        ctx.meta = (n, m, mu_stride, kappa_stride, row0, seed, offset, mu.shape, kappa.shape)
+        if want_logp:
+            ctx.mark_non_differentiable(logp)
+            return z, logp
+        return z
+
+    @staticmethod
+    def backward(ctx, gz, *unused):
+        muc, kc, w, omw = ctx.saved_tensors
+        n, m, mu_stride, kappa_stride, row0, seed, offset, mu_shape, k_shape = ctx.meta
+        dev = muc.device
+        gzc = gz.to(muc.dtype).contiguous()
+        dmu = torch.empty((n, m), device=dev, dtype=muc.dtype)
+        dk = torch.empty((n,), device=dev, dtype=muc.dtype)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().vmf_rsample_bwd(_lib.ptr(muc), mu_stride, _lib.ptr(kc), kappa_stride, _lib.ptr(w),
+                                            _lib.ptr(omw), _lib.ptr(gzc), None, _lib.ptr(dmu), _lib.ptr(dk), n, m,
+                                            row0, seed, offset, _lib.dtype_code(muc), _lib.stream_ptr(dev))
+        _lib.check(rc, "vmf_rsample_bwd")
+        if mu_stride == 0:
+            dmu = dmu.sum(0, keepdim=True)
+        if kappa_stride == 0:
+            dk = dk.sum(0, keepdim=True)
+        return (dmu.view(mu_shape), dk.view(k_shape)) + (None,) * 8
+
+
+class _VMFLogProb(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, kappa, x):
+        dev = _lib.require_hip(mu, kappa, x)
+        n, m = x.shape
+        muc, kc, xc = mu.detach().contiguous(), kappa.detach().contiguous(), x.detach().contiguous()
+        out = torch.empty((n,), device=dev, dtype=mu.dtype)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().vmf_log_prob_fwd(_lib.ptr(muc), m, _lib.ptr(kc), 1, _lib.ptr(xc), _lib.ptr(out), n, m,
+                                             _lib.dtype_code(muc), _lib.stream_ptr(dev))
+        _lib.check(rc, "vmf_log_prob_fwd")
+        ctx.save_for_backward(muc, kc, xc)
+        return out
+
+    @staticmethod
+    def backward(ctx, gl):
+        muc, kc, xc = ctx.saved_tensors
+        n, m = xc.shape
+        dev = muc.device
+        glc = gl.to(muc.dtype).contiguous()
+        dmu, dx, dk = torch.empty_like(muc), torch.empty_like(xc), torch.empty_like(kc)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().vmf_log_prob_bwd(_lib.ptr(muc), m, _lib.ptr(kc), 1, _lib.ptr(xc), _lib.ptr(glc),
+                                             _lib.ptr(dmu), _lib.ptr(dx), _lib.ptr(dk), n, m, _lib.dtype_code(muc),
+                                             _lib.stream_ptr(dev))
+        _lib.check(rc, "vmf_log_prob_bwd")
+        return dmu, dk, dx
+
+
+class _VMFEntropy(torch.autograd.Function):
+    """returns (entropy, KL vs uniform); d KL / d kappa = -d H / d kappa = kappa A_m'(kappa)"""
+
+    @staticmethod
+    def forward(ctx, kappa, m):
+        dev = _lib.require_hip(kappa)
+        kc = kappa.detach().contiguous()
+        H, kl, dkl = torch.empty_like(kc), torch.empty_like(kc), torch.empty_like(kc)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().vmf_entropy_kl_fwd(_lib.ptr(kc), _lib.ptr(H), _lib.ptr(kl), _lib.ptr(dkl), kc.numel(), m,
+                                               _lib.dtype_code(kc), _lib.stream_ptr(dev))
+        _lib.check(rc, "vmf_entropy_kl_fwd")
+        ctx.save_for_backward(dkl)
+        return H, kl
+
+    @staticmethod
+    def backward(ctx, gH, gkl):
+        (dkl,) = ctx.saved_tensors
+        return (gkl - gH) * dkl, None
+
+
+class VonMisesFisher(Distribution):
+    """von Mises-Fisher distribution on S^{m-1} for any m >= 2 (no reference counterpart: the reference asserts
+    m == 3, sampler/von_mises_fisher.py:28).
+
+    loc (..., m) is the mean direction (expected unit-norm), scale (...) or (..., 1) the concentration.
+    rsample: Wood's rejection sampler for w = <z, e1>, a uniform tangent direction from m-1 Gaussians, and the
+    Householder reflection that moves e1 onto loc; all noise is Philox4x32-10 generated inside the kernel and
+    keyed by the global row index (`row_offset` + row), so row-sharded ranks reproduce the unsharded draw."""
+
+    arg_constraints = {"loc": constraints.real, "scale": constraints.positive}  # type: ignore
+    support = constraints.real  # type: ignore
+    has_rsample = True
+
+    def __init__(self, loc, scale, validate_args=None, max_proposals=64, row_offset=0, generator=None):
+        assert loc.shape[-1] >= 2, "VonMisesFisher needs an ambient dimension of at least 2."
+        self.loc = loc
+        self.scale = scale
+        self.device = loc.device
+        self.dtype = loc.dtype
+        self.m = loc.shape[-1]
+        self.max_proposals = int(max_proposals)
+        self.row_offset = int(row_offset)
+        self.generator = generator or rng.default_generator
+        super().__init__(batch_shape=loc.shape[:-1], event_shape=loc.shape[-1:], validate_args=validate_args)
+
+    def _kappa_rows(self):
+        k = self.scale.to(self.dtype)
+        if k.dim() == self.loc.dim() and k.shape[-1] == 1:
+            k = k.squeeze(-1)
+        return k.expand(self.batch_shape).reshape(-1)
+
+    def rsample(self, sample_shape=torch.Size(), return_log_prob=False):
+        sample_shape = torch.Size(sample_shape)
+        nb, S = _numel(self.batch_shape), _numel(sample_shape)
+        n = nb * S
+        mu2d = self.loc.reshape(nb, self.m)
+        kap = self._kappa_rows()
+        if nb == 1 and S > 1:
+            mu_stride, kappa_stride = 0, 0          # one shared mean: nothing is replicated in memory
+        else:
+            mu_stride, kappa_stride = self.m, 1
+            if S > 1:
+                mu2d = mu2d.unsqueeze(0).expand(S, nb, self.m).reshape(n, self.m)
+                kap = kap.unsqueeze(0).expand(S, nb).reshape(n)
+        seed, offset = self.generator.next_offset()
+        out_shape = tuple(sample_shape) + tuple(self.batch_shape)
+        if n == 0:
+            z = torch.empty(out_shape + (self.m,), device=self.device, dtype=self.dtype)
+            return (z, z.new_empty(out_shape)) if return_log_prob else z
+        res = _VMFRSample.apply(mu2d, kap, n, mu_stride, kappa_stride, self.max_proposals, self.row_offset, seed,
+                                offset, bool(return_log_prob))
+        if return_log_prob:
+            z, logp = res
+            return z.view(out_shape + (self.m,)), logp.view(out_shape)
+        return res.view(out_shape + (self.m,))
+
+    def sample(self, sample_shape=torch.Size()):
+        with torch.no_grad():
+            return self.rsample(sample_shape)
+
+    def log_prob(self, x):
+        """kappa <loc, x> + log C_m(kappa)"""
+        bshape = torch.broadcast_shapes(x.shape[:-1], self.batch_shape)
+        n = _numel(bshape)
+        xb = x.to(self.dtype).expand(bshape + (self.m,)).reshape(n, self.m)
+        mub = self.loc.expand(bshape + (self.m,)).reshape(n, self.m)
+        k = self.scale.to(self.dtype)
+        if k.dim() == self.loc.dim() and k.shape[-1] == 1:
+            k = k.squeeze(-1)
+        kb = k.expand(bshape).reshape(n)
+        if n == 0:
+            return xb.new_empty(bshape)
+        return _VMFLogProb.apply(mub, kb, xb).view(bshape)
+
+    def entropy(self):
+        H, _ = _VMFEntropy.apply(self._kappa_rows(), self.m)
+        return H.view(self.batch_shape)
+
+    def kl_uniform(self):
+        """KL(self || U(S^{m-1})) per batch element, in one kernel"""
+        _, kl = _VMFEntropy.apply(self._kappa_rows(), self.m)
+        return kl.view(self.batch_shape)
+
+    @property
+    def mean(self):
+        from .ive import bessel_ratio
+        A = bessel_ratio(self.m / 2, self._kappa_rows().detach()).view(self.batch_shape)
+        return self.loc * A.unsqueeze(-1)
+
+    @property
+    def stddev(self):
+        return self.scale
+
+
+@register_kl(VonMisesFisher, HypersphericalUniform)
+def _kl_vmf_uniform(vmf, hyu):
+    assert hyu.dim + 1 == vmf.m, "dimension mismatch between VonMisesFisher and HypersphericalUniform"
+    return vmf.kl_uniform()

@@ -26,6 +26,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "debye_coeffs.h"
 
@@ -35,6 +38,14 @@
 #ifndef M_LN2
 #define M_LN2 0.69314718055994530942
 #endif
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
 
 /* ---- Philox4x32-10 (Salmon et al. 2011), counter layout shared with the HIP kernels ----------- */
 void orc_philox4x32_10_raw(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {

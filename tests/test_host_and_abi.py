@@ -1,0 +1,197 @@
+"""CPU-side checks: the C ABI library loads and exports every symbol include/vmf_hip.h declares, host logic
+(broadcast plans, error conventions, generator state, module aliases) and the multi-rank path on gloo."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    from medicalimageanalysis_amd import _lib
+
+    hdr = open(os.path.join(ROOT, "include", "vmf_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(\w+)\(", hdr, flags=re.M))
+    assert len(declared) >= 20
+    assert declared == set(_lib.EXPORTS)
+    h = C.CDLL(_lib.library_path())
+    for name in declared:
+        assert hasattr(h, name), name
+    lib = _lib.lib()
+    assert lib.vmf_version() == 100
+    # argument errors are reported without touching a GPU
+    assert lib.vmf_rsample_fwd(None, 64, None, 1, None, None, None, None, None, -1, 64, None, None, 0, None, 64, 0, 0, 0,
+                               0, None) == -1
+    assert b"n < 0" in lib.vmf_last_error_string()
+    assert lib.vmf_rsample_fwd(None, 64, None, 1, None, None, None, None, None, 5, 4096, None, None, 0, None, 64, 0, 0, 0,
+                               0, None) == -4
+    assert lib.vmf_kl_fwd(None, None, None, None, 1.0, 0, 99, 0, None) == -1
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "medicalimageanalysis_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f), errors="replace").read()
+                assert "oracle" not in src.lower().replace("no cpu", ""), os.path.join(dp, f)
+
+
+@pytest.mark.parametrize("loc,scale,ss", [((33, 3), (33,), ()), ((33, 3), (33, 1), ()), ((19, 3), (19,), (5,)),
+                                          ((4, 3), (4, 1), (4,)), ((2, 3, 3), (2, 3), ()), ((3,), (), ()),
+                                          ((7, 3), (1,), (2, 3)), ((1, 3), (6, 1), ())])
+def test_broadcast_plan_matches_numpy_broadcasting(oracle, loc, scale, ss):
+    from medicalimageanalysis_amd.sampler.von_mises_fisher import vmf3_broadcast_plan
+
+    mine = vmf3_broadcast_plan(loc, scale, ss)
+    ref = oracle.vmf3_plan(loc, scale, ss)
+    assert mine["o_shape"] == ref["o_shape"] and mine["w_shape"] == ref["w_shape"] and mine["e_shape"] == ref["e_shape"]
+    odims = mine["odims"]
+    n = int(np.prod(odims))
+    # same operand index for every output row (strides may differ on size-1 dims)
+    idx = np.stack(np.unravel_index(np.arange(n), odims), axis=-1) if n else np.zeros((0, len(odims)), dtype=int)
+    for key in ("w_str", "k_str", "l_str", "e_str"):
+        a = idx @ np.array(mine[key]).reshape(-1)
+        r = np.array(ref[key]) if len(ref[key]) else np.zeros(1, dtype=int)
+        b = idx @ r.reshape(-1)
+        assert np.array_equal(a, b), key
+
+
+def test_broadcast_plan_rejects_incompatible_shapes():
+    from medicalimageanalysis_amd.sampler.von_mises_fisher import vmf3_broadcast_plan
+
+    with pytest.raises(RuntimeError):
+        vmf3_broadcast_plan((5, 3), (4, 1), (3,))  # (3,4,1) vs (3,5): the reference's `*` raises too
+
+
+def test_error_conventions_without_gpu():
+    from medicalimageanalysis_amd.sampler.spherical_uniform import SphericalUniform
+    from medicalimageanalysis_amd.sampler.von_mises_fisher import VonMisesFisher, VonMisesFisher3D
+    from medicalimageanalysis_amd.sampler.ive import ive
+
+    with pytest.raises(AssertionError, match="This simple version o"):
+        VonMisesFisher3D(torch.randn(4, 10), torch.ones(4))
+    with pytest.raises(AssertionError, match="at least 2"):
+        SphericalUniform(1)
+    with pytest.raises(ValueError):
+        VonMisesFisher3D(torch.randn(4, 3), -torch.ones(4), validate_args=True)
+    q = VonMisesFisher3D(torch.randn(4, 3), torch.ones(4))
+    assert q.has_rsample and q.batch_shape == (4,) and callable(q.mean) and callable(q.stddev)
+    np.testing.assert_allclose(q.loc.norm(dim=-1).numpy(), 1.0, atol=2e-4)
+    with pytest.raises(NotImplementedError):
+        q.log_prob(torch.randn(4, 3))
+    with pytest.raises(NotImplementedError):
+        q.entropy()
+    # no CPU path: a CPU tensor is an error, never a silent fallback
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        q.rsample()
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        ive(0.5, torch.ones(3))
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        VonMisesFisher(torch.randn(4, 8), torch.ones(4)).rsample()
+    s = SphericalUniform(3)
+    assert s.event_shape == (3,) and not s.has_rsample
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    code = ("import os; os.environ['VMF_HIP_LIB']=%r\n"
+            "from medicalimageanalysis_amd import _lib\n"
+            "try:\n    _lib.lib()\nexcept RuntimeError as e:\n    print('RAISED', 'no CPU fallback' in str(e))\n"
+            ) % str(tmp_path / "nope.so")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert "RAISED True" in out.stdout, out.stdout + out.stderr
+
+
+def test_generator_state_roundtrip():
+    from medicalimageanalysis_amd.rng import PhiloxGenerator
+
+    g = PhiloxGenerator(seed=7)
+    assert g.next_offset() == (7, 0) and g.next_offset() == (7, 1)
+    st = g.get_state()
+    g.next_offset()
+    g.set_state(st)
+    assert g.next_offset() == (7, 2)
+    g.manual_seed(9)
+    assert g.next_offset() == (9, 0)
+
+
+def test_reference_module_names_resolve():
+    import medicalimageanalysis_amd as pkg
+
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k.split(".")[0] in ("sampler", "model")}
+    try:
+        pkg.install_aliases()
+        ns = {}
+        exec("from sampler.von_mises_fisher import *\nfrom sampler.spherical_uniform import *\n"
+             "from sampler.ive import ive, Ive, IveFunction\nfrom model.spherical_vae import SphericalVAE\n"
+             "from model.torus_vae import ToroidalVAE\n", ns)
+        # the reference's model files rely on these names arriving through the star import
+        for name in ("math", "torch", "ive", "Distribution", "constraints", "VonMisesFisher3D", "SphericalUniform"):
+            assert name in ns, name
+    finally:
+        for k in [k for k in sys.modules if k.split(".")[0] in ("sampler", "model")]:
+            del sys.modules[k]
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})
+
+
+def test_shard_rows_cover_and_order():
+    from medicalimageanalysis_amd.distributed import shard_rows
+
+    for n in (0, 1, 7, 1 << 24, (1 << 24) + 3):
+        for world in (1, 2, 3, 8):
+            spans = [shard_rows(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from medicalimageanalysis_amd.distributed import shard_rows, allreduce_scalars, global_mean
+from oracle import vmf_oracle as orc
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n, m = 1001, 16
+gen = np.random.default_rng(0)
+mu = gen.standard_normal((n, m)); mu /= np.linalg.norm(mu, axis=1, keepdims=True)
+kappa = np.exp(gen.uniform(0, np.log(1e3), n))
+a, b = shard_rows(n, rank, world)
+# each rank samples only its rows, numbered globally
+z, w, idx = orc.vmf_rsample_philox(mu[a:b], kappa[a:b], seed=77, offset=2, row0=a)
+zf, wf, _ = orc.vmf_rsample_philox(mu, kappa, seed=77, offset=2, row0=0)
+assert np.array_equal(z, zf[a:b]) and np.array_equal(w, wf[a:b])
+# the only exchange: one packed all-reduce of the loss scalars
+_, _, s = orc.vmf_kl(kappa[a:b], 4)
+tot = allreduce_scalars(s, float(b - a), torch.tensor(w.sum()))
+_, _, s_full = orc.vmf_kl(kappa, 4)
+assert abs(tot[0].item() - s_full) < 1e-9 * abs(s_full) and tot[1].item() == n
+assert abs(tot[2].item() - wf.sum()) < 1e-9
+gm = global_mean(s, b - a)
+assert abs(gm.item() - s_full / n) < 1e-12
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_rank_gloo_sharding_and_scalar_allreduce(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % {"root": ROOT})
+    port = 29500 + os.getpid() % 2000
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in o, o

@@ -1,0 +1,122 @@
+"""The library's __host__ __device__ per-element math (medicalimageanalysis_amd/csrc/bessel_dev.h, vmf_math.h),
+executed on the CPU through tests/hostcheck/libvmf_hostcheck.so and compared with the oracle and the golden
+vectors.  This checks the arithmetic the kernels run before any GPU is involved; the kernels' indexing,
+cross-lane reductions and launches are covered by the gpu-marked tests.  The check library is test-only: the
+package never loads it."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "hostcheck", "libvmf_hostcheck.so")
+
+
+@pytest.fixture(scope="module")
+def hc():
+    if not os.path.exists(SO):
+        hipcc = "/opt/rocm/bin/hipcc"
+        if not os.path.exists(hipcc):
+            pytest.skip("hipcc not available and hostcheck library not prebuilt")
+        subprocess.check_call([hipcc, "-O2", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-shared", "-o", SO,
+                               os.path.join(HERE, "hostcheck", "hostcheck.hip")])
+    return C.CDLL(SO)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _unary(fn, v, z):
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    out = np.empty_like(z)
+    fn(C.c_double(v), _p(z), _p(out), C.c_int64(z.size))
+    return out
+
+
+def test_device_ive_matches_scipy_goldens(hc, golden):
+    g = golden("g_ive")
+    z = g["z_f64"]
+    for v in g["orders"]:
+        v = float(v)
+        key = f"f64_v{int(v) if v == int(v) else v}"
+        ref_f, ref_b = g["fwd_" + key], g["bwd_" + key]
+        out = _unary(hc.hc_ive_fwd, v, z)
+        np.testing.assert_array_equal(np.isnan(out), np.isnan(ref_f), err_msg=f"v={v}")
+        fin = np.isfinite(ref_f)
+        np.testing.assert_allclose(out[fin], ref_f[fin], rtol=1e-12, atol=1e-300, err_msg=f"v={v}")
+        vm1 = _unary(hc.hc_ive_vm1, v, z)
+        zs = np.where(np.abs(z) < 1e-8, 1e-8, z)
+        with np.errstate(all="ignore"):
+            gz = vm1 - (v / zs + np.sign(z)) * out
+        np.testing.assert_array_equal(np.isnan(gz), np.isnan(ref_b), err_msg=f"bwd v={v}")
+        fin = np.isfinite(ref_b)
+        np.testing.assert_allclose(gz[fin], ref_b[fin], rtol=1e-9, atol=1e-15, err_msg=f"bwd v={v}")
+
+
+def test_device_log_ive_ratio_lognorm_match_oracle(hc, oracle):
+    x = np.logspace(-3, 5, 161)
+    for v in (0.0, 0.5, 1.0, 4.0, 31.0, 32.0, 255.0, 256.0):
+        np.testing.assert_allclose(_unary(hc.hc_log_ive, v, x), oracle.log_ive(v, x), rtol=0,
+                                   atol=3e-12 * (1 + v), err_msg=f"v={v}")
+        if v >= 1:
+            np.testing.assert_allclose(_unary(hc.hc_ratio, v, x), oracle.bessel_ratio(v, x), rtol=2e-10,
+                                       err_msg=f"ratio v={v}")
+    lib = oracle.lib()
+    for m in (2, 3, 10, 64, 512):
+        k = np.logspace(-2, 5, 71)
+        out = np.empty_like(k)
+        hc.hc_log_norm(m, _p(k), _p(out), C.c_int64(k.size))
+        ref = np.array([lib.orc_vmf_log_norm_scalar(m, kk) for kk in k])
+        np.testing.assert_allclose(out, ref, rtol=1e-11, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("name,variant", [("spherical", 0), ("torus", 1), ("circular", 2), ("s1", 3)])
+def test_device_kl_matches_reference(hc, golden, oracle, tag, name, variant):
+    g = golden("g_kl")
+    k = np.ascontiguousarray(g[f"kappa_{tag}"])
+    ref = g[f"{name}_{tag}"]
+    out, dout = np.empty_like(k), np.empty_like(k)
+    getattr(hc, "hc_kl_" + tag)(_p(k), _p(out), _p(dout), C.c_int64(k.size), variant)
+    keep = ~(((k > 709.78) & (k < 710.48)) | ((k > 88.72) & (k < 89.42)))
+    np.testing.assert_array_equal(np.isnan(out)[keep], np.isnan(ref)[keep])
+    fin = np.isfinite(ref) & keep
+    tol = dict(rtol=1e-9, atol=1e-9) if tag == "f64" else dict(rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(out[fin], ref[fin], **tol)
+    o_out, o_d, _ = oracle.vmf_kl(k, variant)
+    fin = np.isfinite(o_d) & np.isfinite(dout) & keep
+    np.testing.assert_allclose(dout[fin], o_d[fin], rtol=1e-6 if tag == "f64" else 2e-3, atol=1e-6)
+
+
+def test_device_rsample_rows_match_reference(hc, golden):
+    g = golden("g_rsample")
+    p = "ew_f64_s0_"
+    loc, scale, u, eps = (np.ascontiguousarray(g[p + k]) for k in ("loc", "scale", "u", "eps"))
+    z = np.empty_like(loc)
+    hc.hc_v3_fwd_f64(_p(loc), _p(scale), _p(u), _p(eps), _p(z), C.c_int64(scale.size))
+    np.testing.assert_allclose(z, g[p + "z"], rtol=0, atol=1e-12)
+    gg = golden("g_grads")
+    loc, scale, u, eps, c = (np.ascontiguousarray(gg["ew_" + k]) for k in ("loc", "scale", "u", "eps", "c"))
+    dloc, dscale = np.empty_like(loc), np.empty_like(scale)
+    hc.hc_v3_bwd_f64(_p(loc), _p(scale), _p(u), _p(eps), _p(c), _p(dloc), _p(dscale), C.c_int64(scale.size))
+    np.testing.assert_allclose(dloc, gg["ew_dloc"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(dscale, gg["ew_dscale"], rtol=1e-9, atol=1e-11)
+
+
+def test_device_wood_accept_index_bit_exact(hc, oracle):
+    rng = np.random.default_rng(11)
+    for m in (3, 10, 64, 512):
+        n, K = 4000, 12
+        kappa = np.exp(rng.uniform(0, np.log(1e5), n))
+        a = (m - 1) / 2
+        pe = np.ascontiguousarray(rng.beta(a, a, size=(n, K)))
+        pu = np.ascontiguousarray(rng.uniform(size=(n, K)))
+        w_ref, idx_ref = oracle.vmf_wood_w(kappa, pe, pu, m)
+        w = np.empty(n)
+        idx = np.empty(n, dtype=np.int32)
+        hc.hc_wood_f64(_p(kappa), _p(pe), _p(pu), _p(w), _p(idx), C.c_int64(n), m, K)
+        np.testing.assert_array_equal(idx, idx_ref)
+        np.testing.assert_allclose(w, w_ref, rtol=0, atol=1e-15)
