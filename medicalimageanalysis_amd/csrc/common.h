@@ -109,12 +109,61 @@ template <> struct M<double> {
   static __device__ __forceinline__ void sincospi2(double u, double* s, double* c) { ::sincospi(2.0 * u, s, c); }
 };
 
+// ---- hot-path math: hardware transcendentals for float, the accurate library for double --------------------
+// v_log_f32 / v_exp_f32 / v_sqrt_f32 / v_rsq_f32 / v_rcp_f32 are 1-ulp single instructions; v_sin_f32 / v_cos_f32
+// take their argument in revolutions, which is exactly what Box-Muller's 2 pi u needs (no range reduction).
+template <typename T> struct F;
+template <> struct F<float> {
+  static __device__ __forceinline__ float log(float x) { return 0.69314718055994530942f * __builtin_amdgcn_logf(x); }
+  static __device__ __forceinline__ float exp(float x) { return __builtin_amdgcn_exp2f(1.44269504088896340736f * x); }
+  static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+  static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+  static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+  static __device__ __forceinline__ void sincos2pi(float u, float* s, float* c) {
+    *s = __builtin_amdgcn_sinf(u);
+    *c = __builtin_amdgcn_cosf(u);
+  }
+  static __device__ __forceinline__ float cos2pi(float u) { return __builtin_amdgcn_cosf(u); }
+  // log(1+s) - s for s > -1: series near 0 (where the difference cancels), direct otherwise
+  static __device__ __forceinline__ float log1p_minus(float s) {
+    if (fabsf(s) < 0.125f) {
+      float s2 = s * s;  // -s^2/2 + s^3/3 - s^4/4 + ... (8 terms: < 1e-8 relative at |s| = 1/8)
+      return s2 * (-0.5f + s * (0.333333333f + s * (-0.25f + s * (0.2f + s * (-0.166666667f + s * (0.142857143f +
+             s * (-0.125f + s * 0.111111111f)))))));
+    }
+    return log(1.0f + s) - s;
+  }
+  // 1 - exp(y) for y <= 0
+  static __device__ __forceinline__ float one_minus_exp(float y) {
+    if (y > -0.0625f) return -y * (1.0f + y * (0.5f + y * (0.166666667f + y * (0.0416666667f + y * 0.00833333333f))));
+    return 1.0f - exp(y);
+  }
+};
+template <> struct F<double> {
+  static __device__ __forceinline__ double log(double x) { return ::log(x); }
+  static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+  static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+  static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
+  static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+  static __device__ __forceinline__ void sincos2pi(double u, double* s, double* c) { ::sincospi(2.0 * u, s, c); }
+  static __device__ __forceinline__ double cos2pi(double u) { return ::cospi(2.0 * u); }
+  static __device__ __forceinline__ double log1p_minus(double s) {
+    if (::fabs(s) < 1e-2) {
+      double s2 = s * s, acc = 0.0;  // 12 terms: < 1e-24 relative at |s| = 1e-2
+      for (int k = 13; k >= 2; --k) acc = acc * s + ((k & 1) ? 1.0 : -1.0) / (double)k;
+      return s2 * acc;
+    }
+    return ::log1p(s) - s;
+  }
+  static __device__ __forceinline__ double one_minus_exp(double y) { return -::expm1(y); }
+};
+
 // Box-Muller on two uniforms: (sqrt(-2 ln u0) cos 2pi u1, sqrt(-2 ln u0) sin 2pi u1)
 template <typename T>
 __device__ __forceinline__ void box_muller(T u0, T u1, T* n0, T* n1) {
-  T r = M<T>::sqrt((T)-2 * M<T>::log(u0));
+  T r = F<T>::sqrt((T)-2 * F<T>::log(u0));
   T s, c;
-  M<T>::sincospi2(u1, &s, &c);
+  F<T>::sincos2pi(u1, &s, &c);
   *n0 = r * c;
   *n1 = r * s;
 }

@@ -62,13 +62,14 @@ __device__ __forceinline__ void store4(T* __restrict__ rowp, int e0, int m, cons
   }
 }
 
-// normals for elements [e0, e0+4) of global row `grow`; element 0 and elements >= m are zeroed
+// normals for elements [e0, e0+4) of global row `grow` (grow_ptr: that row of the pre-drawn normals, or null for the
+// counter-based stream); element 0 and elements >= m are zeroed
 template <typename T, bool VEC>
-__device__ __forceinline__ void noise4(const T* __restrict__ gauss, int64_t row, uint64_t grow, int chunk, int m,
-                                       PhiloxKey key, T g[4]) {
+__device__ __forceinline__ void noise4(const T* __restrict__ grow_ptr, uint64_t grow, int chunk, int m, PhiloxKey key,
+                                       T g[4]) {
   int e0 = 4 * chunk;
-  if (gauss) {
-    load4<T, VEC>(gauss + row * (int64_t)m, e0, m, g);
+  if (grow_ptr) {
+    load4<T, VEC>(grow_ptr, e0, m, g);
   } else if (e0 < m) {
     philox_normal4<T>(grow, SLOT_GAUSS + (uint32_t)chunk, key, g);
   } else {
@@ -79,66 +80,85 @@ __device__ __forceinline__ void noise4(const T* __restrict__ gauss, int64_t row,
     if (e0 + i >= m || e0 + i == 0) g[i] = (T)0;
 }
 
-template <typename T, int LPR, int P, bool VEC>
-__global__ __launch_bounds__(WAVES * 64) void vmf_rsample_fwd_kernel(GenParams<T> p) {
+// Forward kernel.  MODE 0: scalar element access (m % 4 != 0 or unaligned rows), bounds checks, pre-drawn noise
+// allowed.  MODE 1: 128-bit access, bounds checks (m < 4 LPR P), pre-drawn noise allowed.  MODE 2: the streaming
+// configuration -- m == 4 LPR P exactly, 128-bit access, counter-based noise only, no per-element guards.
+template <typename T>
+struct FwdParams {
+  const T* mu; const T* kappa; T* z;
+  T* w_out; T* omw_out; int32_t* accept_idx; T* logp;
+  const T* prop_e; const T* prop_u; const T* gauss;
+  int64_t n; uint64_t row0;
+  int mu_stride, kappa_stride, m, max_prop;
+  PhiloxKey key;
+};
+
+template <typename T, int LPR, int P, int MODE>
+__global__ __launch_bounds__(WAVES * 64) void vmf_rsample_fwd_kernel(FwdParams<T> p) {
+  constexpr bool VEC = MODE >= 1;
+  constexpr bool FAST = MODE == 2;
   __shared__ T s_w[WAVES][TILE_ROWS];
   __shared__ T s_omw[WAVES][TILE_ROWS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int RPI = 64 / LPR;  // rows per wave step
   const int sub = lane % LPR, grp = lane / LPR;
-  const int m = p.m;
+  const int m = FAST ? 4 * LPR * P : p.m;
   const int64_t n_tiles = (p.n + TILE_ROWS - 1) / TILE_ROWS;
   const int64_t tiles_per_sweep = (int64_t)gridDim.x * WAVES;
   const int64_t n_sweeps = (n_tiles + tiles_per_sweep - 1) / tiles_per_sweep;  // same for every wave of the grid
+  const bool pre = !FAST && p.prop_e != nullptr;
+  T* const sw = s_w[wave];
+  T* const somw = s_omw[wave];
 
   for (int64_t sweep = 0; sweep < n_sweeps; ++sweep) {
     const int64_t tile = (sweep * gridDim.x + blockIdx.x) * WAVES + wave;
-    const int64_t tile0 = tile * TILE_ROWS;
-    int64_t left = p.n - tile0;
+    const int64_t tile0 = tile * TILE_ROWS;  // wave-uniform
+    const int64_t left = p.n - tile0;
     const int ntile = left <= 0 ? 0 : (left < TILE_ROWS ? (int)left : TILE_ROWS);
+    const T* const kap_t = p.kappa + tile0 * p.kappa_stride;
+    const uint64_t grow0 = p.row0 + (uint64_t)tile0;
 
-    // ---- phase 1: rejection sampler, one row per lane, accepted lanes refill from the tile's queue ----
+    // ---- phase 1: rejection sampler, one row per lane; accepted lanes retire their row and are refilled with
+    //      the next unassigned row of the tile (ballot + prefix popcount) ----
     {
       int my = lane, next = 64, k = 0;
       bool active = my < ntile;
-      T a = 0, b = 0, d = 0, kap = 1;
+      T a = 0, b = 0, d = 0;
       if (active) {
-        kap = p.kappa[(tile0 + my) * p.kappa_stride];
-        wood_consts<T>(kap, m, &a, &b, &d);
+        const T kap = kap_t[my * p.kappa_stride];
+        if (pre) wood_consts<T>(kap, m, &a, &b, &d);
+        else b = wood_b<T>(kap, m);
       }
       while (__ballot(active) != 0ull) {
         bool acc = false;
         if (active) {
-          const int64_t row = tile0 + my;
-          T e, ua, w, omw;
-          if (p.prop_e) {
-            e = p.prop_e[row * p.max_prop + k];
-            ua = p.prop_u[row * p.max_prop + k];
+          T w, omw;
+          if (pre) {
+            const int64_t row = tile0 + my;
+            acc = wood_try<T>(a, b, d, m, p.prop_e[row * p.max_prop + k], p.prop_u[row * p.max_prop + k], &w, &omw);
           } else {
-            U4 r = philox4x32_10(p.row0 + (uint64_t)row, (uint32_t)k, p.key);
-            e = sym_beta<T>(u01<T>(r.x), u01<T>(r.y), m);
-            ua = u01<T>(r.z);
+            const U4 r = philox4x32_10(grow0 + (uint64_t)my, (uint32_t)k, p.key);
+            acc = wood_try_counter<T>(b, m, u01<T>(r.x), u01<T>(r.y), u01<T>(r.z), &w, &omw);
           }
-          acc = wood_try<T>(a, b, d, m, e, ua, &w, &omw);
           if (k + 1 >= p.max_prop) acc = true;  // the last proposal allowed is taken regardless
           if (acc) {
-            s_w[wave][my] = w;
-            s_omw[wave][my] = omw;
-            if (p.w_out) p.w_out[row] = w;
-            if (p.omw_out) p.omw_out[row] = omw;
-            if (p.accept_idx) p.accept_idx[row] = k;
+            sw[my] = w;
+            somw[my] = omw;
+            if (p.w_out) p.w_out[tile0 + my] = w;
+            if (p.omw_out) p.omw_out[tile0 + my] = omw;
+            if (p.accept_idx) p.accept_idx[tile0 + my] = k;
           }
           ++k;
         }
         const unsigned long long accm = __ballot(acc);
         if (acc) {
-          const int rank = __popcll(accm & ((1ull << lane) - 1ull));
-          my = next + rank;
+          my = next + __popcll(accm & ((1ull << lane) - 1ull));
           k = 0;
           active = my < ntile;
           if (active) {
-            kap = p.kappa[(tile0 + my) * p.kappa_stride];
-            wood_consts<T>(kap, m, &a, &b, &d);
+            const T kap = kap_t[my * p.kappa_stride];
+            if (pre) wood_consts<T>(kap, m, &a, &b, &d);
+            else b = wood_b<T>(kap, m);
           }
         }
         next += __popcll(accm);
@@ -147,21 +167,31 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_fwd_kernel(GenParams<T
     __syncthreads();
 
     // ---- phase 2: stream the tile's rows, RPI rows per step ----
+    const T* const mu_t = p.mu + tile0 * p.mu_stride;
+    T* const z_t = p.z + tile0 * m;
+    const T* const ga_t = (!FAST && p.gauss) ? p.gauss + tile0 * m : nullptr;
     for (int r0 = 0; r0 < ntile; r0 += RPI) {
       const int r = r0 + grp;
       const bool valid = r < ntile;
-      const int64_t row = tile0 + (valid ? r : 0);
-      const T* mrow = p.mu + row * p.mu_stride;
+      const int rr = valid ? r : 0;
+      const T* mrow = mu_t + rr * p.mu_stride;
       T mu[P][4], g[P][4];
       T gg = 0, dd = 0, gm = 0;
 #pragma unroll
       for (int j = 0; j < P; ++j) {
         const int chunk = j * LPR + sub;
-        load4<T, VEC>(mrow, 4 * chunk, m, mu[j]);
-        noise4<T, VEC>(p.gauss, row, p.row0 + (uint64_t)row, chunk, m, p.key, g[j]);
+        if (FAST) {
+          const Vec4<T> v = *reinterpret_cast<const Vec4<T>*>(mrow + 4 * chunk);
+          mu[j][0] = v.v[0]; mu[j][1] = v.v[1]; mu[j][2] = v.v[2]; mu[j][3] = v.v[3];
+          philox_normal4<T>(grow0 + (uint64_t)rr, SLOT_GAUSS + (uint32_t)chunk, p.key, g[j]);
+          if (j == 0 && sub == 0) g[0][0] = (T)0;
+        } else {
+          load4<T, VEC>(mrow, 4 * chunk, m, mu[j]);
+          noise4<T, VEC>(ga_t ? ga_t + (int64_t)rr * m : nullptr, grow0 + (uint64_t)rr, chunk, m, p.key, g[j]);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const bool first = (chunk == 0 && i == 0);
+          const bool first = (j == 0 && i == 0 && sub == 0);
           const T dmu = first ? (T)1 - mu[j][i] : mu[j][i];
           gg += g[j][i] * g[j][i];
           dd += dmu * dmu;
@@ -171,31 +201,37 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_fwd_kernel(GenParams<T
       gg = group_allreduce_sum<LPR, T>(gg);
       dd = group_allreduce_sum<LPR, T>(dd);
       gm = group_allreduce_sum<LPR, T>(gm);
-      const T mu0 = __shfl(mu[0][0], lane - sub, 64);
-      const T w = s_w[wave][valid ? r : 0], omw = s_omw[wave][valid ? r : 0];
+      const T mu0 = LPR == 1 ? mu[0][0] : __shfl(mu[0][0], lane - sub, 64);
+      const T w = sw[rr], omw = somw[rr];
       T c2 = omw * ((T)1 + w);
       c2 = c2 < (T)1e-10 ? (T)1e-10 : c2;
-      const T f = M<T>::sqrt(c2) / M<T>::sqrt(gg);
+      const T f = F<T>::sqrt(c2) * F<T>::rsqrt(gg);
       const T d0 = (T)1 - mu0;
       const T zd = w * d0 - f * gm;
-      const T coef = dd > (T)1e-30 ? (T)2 * zd / dd : (T)0;
+      const T coef = dd > (T)1e-30 ? (T)2 * zd * F<T>::rcp(dd) : (T)0;
       if (valid) {
-        T* zrow = p.z + row * (int64_t)m;
+        T* zrow = z_t + rr * m;
 #pragma unroll
         for (int j = 0; j < P; ++j) {
           const int chunk = j * LPR + sub;
           T out[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const bool first = (chunk == 0 && i == 0);
+            const bool first = (j == 0 && i == 0 && sub == 0);
             out[i] = first ? w - coef * d0 : f * g[j][i] + coef * mu[j][i];
           }
-          store4<T, VEC>(zrow, 4 * chunk, m, out);
+          if (FAST) {
+            Vec4<T> v;
+            v.v[0] = out[0]; v.v[1] = out[1]; v.v[2] = out[2]; v.v[3] = out[3];
+            *reinterpret_cast<Vec4<T>*>(zrow + 4 * chunk) = v;
+          } else {
+            store4<T, VEC>(zrow, 4 * chunk, m, out);
+          }
         }
         if (p.logp && sub == 0) {
-          const T mm = dd - (T)1 + (T)2 * mu0;                       // |mu|^2
-          const T mz = w * mu0 + f * gm - coef * (mu0 - mm);         // <mu, z>
-          p.logp[row] += p.kappa[row * p.kappa_stride] * mz;  // log C_m(kappa) was stored by the pre-pass
+          const T mm = dd - (T)1 + (T)2 * mu0;                // |mu|^2
+          const T mz = w * mu0 + f * gm - coef * (mu0 - mm);  // <mu, z>
+          p.logp[tile0 + rr] += kap_t[rr * p.kappa_stride] * mz;  // log C_m(kappa) was stored by the pre-pass
         }
       }
     }
@@ -226,7 +262,7 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
       const int chunk = j * LPR + sub;
       load4<T, VEC>(mrow, 4 * chunk, m, mu[j]);
       load4<T, VEC>(grow_, 4 * chunk, m, G[j]);
-      noise4<T, VEC>(p.gauss, row, p.row0 + (uint64_t)row, chunk, m, p.key, g[j]);
+      noise4<T, VEC>(p.gauss ? p.gauss + row * (int64_t)m : nullptr, p.row0 + (uint64_t)row, chunk, m, p.key, g[j]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bool first = (chunk == 0 && i == 0);
@@ -299,32 +335,36 @@ __global__ __launch_bounds__(256) void vmf_log_norm_kernel(const T* __restrict__
 }
 
 // ---- launch plumbing ---------------------------------------------------------------------------------
-template <typename T, int LPR, int P, bool VEC, bool BWD>
-static void launch_one(const GenParams<T>& p, int grid, hipStream_t s) {
-  if (BWD)
-    hipLaunchKernelGGL((vmf_rsample_bwd_kernel<T, LPR, P, VEC>), dim3(grid), dim3(WAVES * 64), 0, s, p);
-  else
-    hipLaunchKernelGGL((vmf_rsample_fwd_kernel<T, LPR, P, VEC>), dim3(grid), dim3(WAVES * 64), 0, s, p);
+#define VMF_SHAPE_SWITCH(chunks, CALL)                 \
+  do {                                                 \
+    if ((chunks) <= 1) { CALL(1, 1); }                 \
+    else if ((chunks) <= 2) { CALL(2, 1); }            \
+    else if ((chunks) <= 4) { CALL(4, 1); }            \
+    else if ((chunks) <= 8) { CALL(8, 1); }            \
+    else if ((chunks) <= 16) { CALL(16, 1); }          \
+    else if ((chunks) <= 32) { CALL(32, 1); }          \
+    else if ((chunks) <= 64) { CALL(64, 1); }          \
+    else if ((chunks) <= 128) { CALL(64, 2); }         \
+    else if ((chunks) <= 256) { CALL(64, 4); }         \
+    else { CALL(64, 8); }                              \
+  } while (0)
+
+template <typename T, int MODE>
+static void launch_fwd(const FwdParams<T>& p, int grid, hipStream_t s) {
+  const int chunks = (p.m + 3) / 4;
+#define VMF_CALL(L, PP) \
+  hipLaunchKernelGGL((vmf_rsample_fwd_kernel<T, L, PP, MODE>), dim3(grid), dim3(WAVES * 64), 0, s, p)
+  VMF_SHAPE_SWITCH(chunks, VMF_CALL);
+#undef VMF_CALL
 }
 
-template <typename T, bool VEC, bool BWD>
-static int launch_shape(const GenParams<T>& p, int grid, hipStream_t s) {
+template <typename T, bool VEC>
+static void launch_bwd(const GenParams<T>& p, int grid, hipStream_t s) {
   const int chunks = (p.m + 3) / 4;
-  if (chunks <= 1) launch_one<T, 1, 1, VEC, BWD>(p, grid, s);
-  else if (chunks <= 2) launch_one<T, 2, 1, VEC, BWD>(p, grid, s);
-  else if (chunks <= 4) launch_one<T, 4, 1, VEC, BWD>(p, grid, s);
-  else if (chunks <= 8) launch_one<T, 8, 1, VEC, BWD>(p, grid, s);
-  else if (chunks <= 16) launch_one<T, 16, 1, VEC, BWD>(p, grid, s);
-  else if (chunks <= 32) launch_one<T, 32, 1, VEC, BWD>(p, grid, s);
-  else if (chunks <= 64) launch_one<T, 64, 1, VEC, BWD>(p, grid, s);
-  else if (chunks <= 128) launch_one<T, 64, 2, VEC, BWD>(p, grid, s);
-  else if (chunks <= 256) launch_one<T, 64, 4, VEC, BWD>(p, grid, s);
-  else if (chunks <= 512) launch_one<T, 64, 8, VEC, BWD>(p, grid, s);
-  else {
-    vmf_set_error("m=%d > 2048 is not supported", p.m);
-    return VMF_ERR_UNSUPPORTED;
-  }
-  return VMF_OK;
+#define VMF_CALL(L, PP) \
+  hipLaunchKernelGGL((vmf_rsample_bwd_kernel<T, L, PP, VEC>), dim3(grid), dim3(WAVES * 64), 0, s, p)
+  VMF_SHAPE_SWITCH(chunks, VMF_CALL);
+#undef VMF_CALL
 }
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
@@ -334,20 +374,29 @@ static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
                          void* w_out, void* omw_out, int32_t* accept_idx, void* logp_out, int64_t n, int m,
                          const void* prop_e, const void* prop_u, int n_prop, const void* gauss, int max_prop,
                          uint64_t row0, uint64_t seed, uint64_t offset, hipStream_t s) {
-  GenParams<T> p = {};
-  p.mu = (const T*)mu; p.mu_stride = mu_stride; p.kappa = (const T*)kappa; p.kappa_stride = kappa_stride;
-  p.z = (T*)z; p.w_out = (T*)w_out; p.omw_out = (T*)omw_out; p.accept_idx = accept_idx; p.logp = (T*)logp_out;
+  FwdParams<T> p = {};
+  p.mu = (const T*)mu; p.kappa = (const T*)kappa; p.z = (T*)z;
+  p.w_out = (T*)w_out; p.omw_out = (T*)omw_out; p.accept_idx = accept_idx; p.logp = (T*)logp_out;
   p.prop_e = (const T*)prop_e; p.prop_u = (const T*)prop_u; p.gauss = (const T*)gauss;
-  p.n = n; p.m = m; p.max_prop = prop_e ? n_prop : max_prop; p.row0 = row0;
-  p.key = make_philox_key(seed, offset); p.dim = make_vmf_dim(m);
+  p.n = n; p.row0 = row0; p.mu_stride = (int)mu_stride; p.kappa_stride = (int)kappa_stride; p.m = m;
+  p.max_prop = prop_e ? n_prop : max_prop;
+  p.key = make_philox_key(seed, offset);
   const bool vec = (m % 4 == 0) && (mu_stride % 4 == 0) && aligned16(mu) && aligned16(z) && (!gauss || aligned16(gauss));
+  const int chunks = (m + 3) / 4;
+  int lpr = 1;
+  while (lpr < chunks && lpr < 64) lpr *= 2;
+  const int passes = (chunks + lpr - 1) / lpr;
+  const bool full = vec && (passes == 1 || passes == 2 || passes == 4 || passes == 8) && m == 4 * lpr * passes;
   const int64_t n_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
   int64_t gb = (n_tiles + WAVES - 1) / WAVES;
   const int grid = (int)(gb < 1 ? 1 : (gb > 2048 ? 2048 : gb));
   if (logp_out)
     hipLaunchKernelGGL(vmf_log_norm_kernel<T>, dim3(vmf_grid_for(n, 256)), dim3(256), 0, s, (const T*)kappa,
-                       kappa_stride, (T*)logp_out, n, p.dim);
-  return vec ? launch_shape<T, true, false>(p, grid, s) : launch_shape<T, false, false>(p, grid, s);
+                       kappa_stride, (T*)logp_out, n, make_vmf_dim(m));
+  if (full && !prop_e) launch_fwd<T, 2>(p, grid, s);
+  else if (vec) launch_fwd<T, 1>(p, grid, s);
+  else launch_fwd<T, 0>(p, grid, s);
+  return VMF_OK;
 }
 
 extern "C" int vmf_rsample_fwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, void* z,
@@ -393,7 +442,9 @@ static int rsample_bwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   const int64_t steps = (n + (64 / lpr) - 1) / (64 / lpr);
   int64_t gb = (steps + WAVES - 1) / WAVES;
   const int grid = (int)(gb < 1 ? 1 : (gb > 2048 ? 2048 : gb));
-  return vec ? launch_shape<T, true, true>(p, grid, s) : launch_shape<T, false, true>(p, grid, s);
+  if (vec) launch_bwd<T, true>(p, grid, s);
+  else launch_bwd<T, false>(p, grid, s);
+  return VMF_OK;
 }
 
 extern "C" int vmf_rsample_bwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride,

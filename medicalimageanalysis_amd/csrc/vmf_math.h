@@ -181,12 +181,27 @@ VMF_HD bool wood_try(T a, T b, T d, int m, T e, T uacc, T* w, T* omw) {
   return lhs >= ::log((double)uacc);
 }
 
-// symmetric Beta((m-1)/2,(m-1)/2) from two uniforms (Ulrich 1984): 1/2 (1 + sqrt(1 - U^(2/(m-2))) cos 2 pi V)
+// Counter-based proposal (hot path).  With c = 2e - 1 = sqrt(1 - U^(2/(m-2))) cos 2 pi V (Ulrich 1984: e is
+// symmetric Beta((m-1)/2,(m-1)/2)) the proposal and the accept test are written without cancellation:
+//   den = 1 - (1-b)(1+c)/2,  1 - w = b (1+c)/den,  w = 1 - (1-w)
+//   4ab/(1+b) = m-1 identically, so  (m-1) ln t - t + d = (m-1) [log(1+s) - s],  s = t/(m-1) - 1 = (1-b) c / (2 den)
+// and the test is (m-1)[log1p(s) - s] >= ln u.  Same decision as wood_try up to rounding.
 template <typename T>
-__device__ __forceinline__ T sym_beta(T U, T V, int m) {
-  T s = (T)1;
-  if (m > 2) s = -M<T>::expm1((T)2 / (T)(m - 2) * M<T>::log(U));
-  T sn, cs;
-  M<T>::sincospi2(V, &sn, &cs);
-  return (T)0.5 + (T)0.5 * M<T>::sqrt(s) * cs;
+__device__ __forceinline__ bool wood_try_counter(T b, int m, T U, T V, T uacc, T* w, T* omw) {
+  T sq = (T)1;
+  if (m > 2) sq = F<T>::one_minus_exp((T)2 / (T)(m - 2) * F<T>::log(U));
+  const T c = F<T>::sqrt(sq) * F<T>::cos2pi(V);
+  const T den = (T)1 - (T)0.5 * ((T)1 - b) * ((T)1 + c);
+  const T rden = F<T>::rcp(den);
+  *omw = b * ((T)1 + c) * rden;
+  *w = (T)1 - *omw;
+  const T s = (T)0.5 * ((T)1 - b) * c * rden;
+  return (T)(m - 1) * F<T>::log1p_minus(s) >= F<T>::log(uacc);
+}
+
+// b(kappa) alone (what the counter-based path needs)
+template <typename T>
+__device__ __forceinline__ T wood_b(T kappa, int m) {
+  const T m1 = (T)(m - 1);
+  return m1 * F<T>::rcp((T)2 * kappa + F<T>::sqrt((T)4 * kappa * kappa + m1 * m1));
 }
