@@ -81,7 +81,8 @@ __device__ __forceinline__ U4 philox4x32_10(uint64_t index, uint32_t slot, Philo
 // 23-bit uniform strictly inside (0,1): ((x >> 9) + 1/2) * 2^-23, exact in fp32 and fp64.
 template <typename T>
 __device__ __forceinline__ T u01(uint32_t x) {
-  return ((T)(x >> 9) + (T)0.5) * (T)(1.0 / 8388608.0);
+  // one shift, one convert, one fma; every step is exact
+  return (T)(x >> 9) * (T)(1.0 / 8388608.0) + (T)(1.0 / 16777216.0);
 }
 
 // ---- type-generic math: accurate (ocml) versions --------------------------------------------
@@ -114,6 +115,8 @@ template <> struct M<double> {
 // take their argument in revolutions, which is exactly what Box-Muller's 2 pi u needs (no range reduction).
 template <typename T> struct F;
 template <> struct F<float> {
+  static __device__ __forceinline__ float log2(float x) { return __builtin_amdgcn_logf(x); }
+  static __device__ __forceinline__ float exp2(float x) { return __builtin_amdgcn_exp2f(x); }
   static __device__ __forceinline__ float log(float x) { return 0.69314718055994530942f * __builtin_amdgcn_logf(x); }
   static __device__ __forceinline__ float exp(float x) { return __builtin_amdgcn_exp2f(1.44269504088896340736f * x); }
   static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -124,22 +127,22 @@ template <> struct F<float> {
     *c = __builtin_amdgcn_cosf(u);
   }
   static __device__ __forceinline__ float cos2pi(float u) { return __builtin_amdgcn_cosf(u); }
-  // log(1+s) - s for s > -1: series near 0 (where the difference cancels), direct otherwise
-  static __device__ __forceinline__ float log1p_minus(float s) {
-    if (fabsf(s) < 0.125f) {
-      float s2 = s * s;  // -s^2/2 + s^3/3 - s^4/4 + ... (8 terms: < 1e-8 relative at |s| = 1/8)
-      return s2 * (-0.5f + s * (0.333333333f + s * (-0.25f + s * (0.2f + s * (-0.166666667f + s * (0.142857143f +
-             s * (-0.125f + s * 0.111111111f)))))));
-    }
-    return log(1.0f + s) - s;
+  // (log(1+s) - s) / ln 2 for s > -1, evaluated directly: the rounding of 1+s bounds the absolute error by
+  // 2^-24 / ln 2, which the caller multiplies by (m-1) -- negligible against log2 of a uniform.
+  static __device__ __forceinline__ float log1p_minus_over_ln2(float s) {
+    return __builtin_amdgcn_logf(1.0f + s) - 1.44269504088896340736f * s;
   }
-  // 1 - exp(y) for y <= 0
-  static __device__ __forceinline__ float one_minus_exp(float y) {
-    if (y > -0.0625f) return -y * (1.0f + y * (0.5f + y * (0.166666667f + y * (0.0416666667f + y * 0.00833333333f))));
-    return 1.0f - exp(y);
+  // 1 - 2^t for t <= 0 (t = y / ln 2): short series where the difference cancels
+  static __device__ __forceinline__ float one_minus_exp2(float t) {
+    const float y = 0.69314718055994530942f * t;
+    const float poly = -y * (1.0f + y * (0.5f + y * (0.166666667f + y * 0.0416666667f)));
+    const float direct = 1.0f - __builtin_amdgcn_exp2f(t);
+    return y > -0.03125f ? poly : direct;
   }
 };
 template <> struct F<double> {
+  static __device__ __forceinline__ double log2(double x) { return ::log2(x); }
+  static __device__ __forceinline__ double exp2(double x) { return ::exp2(x); }
   static __device__ __forceinline__ double log(double x) { return ::log(x); }
   static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
@@ -147,21 +150,24 @@ template <> struct F<double> {
   static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
   static __device__ __forceinline__ void sincos2pi(double u, double* s, double* c) { ::sincospi(2.0 * u, s, c); }
   static __device__ __forceinline__ double cos2pi(double u) { return ::cospi(2.0 * u); }
-  static __device__ __forceinline__ double log1p_minus(double s) {
+  static __device__ __forceinline__ double log1p_minus_over_ln2(double s) {
+    double r;
     if (::fabs(s) < 1e-2) {
-      double s2 = s * s, acc = 0.0;  // 12 terms: < 1e-24 relative at |s| = 1e-2
+      double acc = 0.0;  // s^2 (-1/2 + s/3 - s^2/4 ...), 12 terms: < 1e-24 relative at |s| = 1e-2
       for (int k = 13; k >= 2; --k) acc = acc * s + ((k & 1) ? 1.0 : -1.0) / (double)k;
-      return s2 * acc;
+      r = s * s * acc;
+    } else {
+      r = ::log1p(s) - s;
     }
-    return ::log1p(s) - s;
+    return r * 1.44269504088896340736;
   }
-  static __device__ __forceinline__ double one_minus_exp(double y) { return -::expm1(y); }
+  static __device__ __forceinline__ double one_minus_exp2(double t) { return -::expm1(0.69314718055994530942 * t); }
 };
 
 // Box-Muller on two uniforms: (sqrt(-2 ln u0) cos 2pi u1, sqrt(-2 ln u0) sin 2pi u1)
 template <typename T>
 __device__ __forceinline__ void box_muller(T u0, T u1, T* n0, T* n1) {
-  T r = F<T>::sqrt((T)-2 * F<T>::log(u0));
+  T r = F<T>::sqrt((T)-1.38629436111989061883 * F<T>::log2(u0));  // -2 ln u0
   T s, c;
   F<T>::sincos2pi(u1, &s, &c);
   *n0 = r * c;

@@ -189,14 +189,14 @@ VMF_HD bool wood_try(T a, T b, T d, int m, T e, T uacc, T* w, T* omw) {
 template <typename T>
 __device__ __forceinline__ bool wood_try_counter(T b, int m, T U, T V, T uacc, T* w, T* omw) {
   T sq = (T)1;
-  if (m > 2) sq = F<T>::one_minus_exp((T)2 / (T)(m - 2) * F<T>::log(U));
+  if (m > 2) sq = F<T>::one_minus_exp2((T)2 / (T)(m - 2) * F<T>::log2(U));  // 1 - U^(2/(m-2))
   const T c = F<T>::sqrt(sq) * F<T>::cos2pi(V);
   const T den = (T)1 - (T)0.5 * ((T)1 - b) * ((T)1 + c);
   const T rden = F<T>::rcp(den);
   *omw = b * ((T)1 + c) * rden;
   *w = (T)1 - *omw;
   const T s = (T)0.5 * ((T)1 - b) * c * rden;
-  return (T)(m - 1) * F<T>::log1p_minus(s) >= F<T>::log(uacc);
+  return (T)(m - 1) * F<T>::log1p_minus_over_ln2(s) >= F<T>::log2(uacc);  // both sides divided by ln 2
 }
 
 // b(kappa) alone (what the counter-based path needs)

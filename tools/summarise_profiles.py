@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 outputs under gpurun_out/ into the small, tracked summaries under profiles/.
+
+  python tools/summarise_profiles.py stats  gpurun_out/prof_X  profiles/NAME.csv   # --kernel-trace --stats
+  python tools/summarise_profiles.py pmc    gpurun_out/pmc_fetch gpurun_out/pmc_write [more pmc dirs] \
+         --rows 16777216 --m 64 --out profiles/traffic_latest.json --csv profiles/NAME_pmc.csv
+
+HBM traffic follows the gfx950 rules for rocprofv3: FETCH_SIZE and WRITE_SIZE are reported in KiB by separate
+passes; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream, so it is doubled; WRITE_SIZE is
+exact for 16-B-per-lane streaming stores.
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def stats(src, dst):
+    f = glob.glob(os.path.join(src, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    rows = list(csv.DictReader(open(f)))
+    with open(dst, "w", newline="") as out:
+        w = csv.writer(out)
+        w.writerow(["Name(truncated to 100 chars)", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows:
+            w.writerow([r["Name"][:100], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
+                        r["MaxNs"]])
+    print("wrote", dst)
+
+
+def pmc(dirs, rows, m, out_json, out_csv, kernel="vmf_rsample_fwd"):
+    agg = collections.defaultdict(list)
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if kernel in r["Kernel_Name"]:
+                    agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    mean = {k: sum(v) / len(v) for k, v in agg.items()}
+    with open(out_csv, "w", newline="") as out:
+        w = csv.writer(out)
+        w.writerow(["counter", "dispatches", "mean_per_dispatch"])
+        for k in sorted(mean):
+            w.writerow([k, len(agg[k]), mean[k]])
+    res = {"rows": rows, "m": m, "kernel": kernel}
+    if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
+        fetch_b = mean["FETCH_SIZE"] * 1024 * 2  # gfx950: doubled
+        write_b = mean["WRITE_SIZE"] * 1024
+        res.update({"fetch_bytes_corrected": fetch_b, "write_bytes": write_b, "hbm_bytes_per_launch": fetch_b + write_b,
+                    "algorithmic_bytes_per_launch": rows * (2 * m + 1) * 4})
+    with open(out_json, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        ap = argparse.ArgumentParser()
+        ap.add_argument("mode")
+        ap.add_argument("dirs", nargs="+")
+        ap.add_argument("--rows", type=int, default=1 << 24)
+        ap.add_argument("--m", type=int, default=64)
+        ap.add_argument("--out", default="profiles/traffic_latest.json")
+        ap.add_argument("--csv", default="profiles/pmc_latest.csv")
+        a = ap.parse_args()
+        pmc(a.dirs, a.rows, a.m, a.out, a.csv)
