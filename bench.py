@@ -77,11 +77,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    if a.gpus != world and rank == 0:
-        print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        os.environ.setdefault("MASTER_PORT", "29511")
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if a.gpus != world and rank == 0:
+        print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
     from medicalimageanalysis_amd import _lib
 

@@ -18,8 +18,15 @@
 //   memory.
 #include "vmf_math.h"
 
-constexpr int TILE_ROWS = 128;
-constexpr int WAVES = 4;
+// build-time tuning knobs (defaults are the measured optimum on MI355X for m = 64 fp32)
+#ifndef VMF_TILE_ROWS
+#define VMF_TILE_ROWS 128
+#endif
+#ifndef VMF_WAVES
+#define VMF_WAVES 4
+#endif
+constexpr int TILE_ROWS = VMF_TILE_ROWS;
+constexpr int WAVES = VMF_WAVES;
 constexpr uint32_t SLOT_GAUSS = 0x10000u;
 constexpr int BWD_STEPS = 16;
 
@@ -541,51 +548,122 @@ extern "C" int vmf_rsample_bwd(const void* mu, int64_t mu_stride, const void* ka
 }
 
 // ---- log_prob, entropy, KL ----------------------------------------------------------------------------
-// log_prob: a wave takes one row at a time, lanes stride over the row (coalesced), wave reduction.
+// log_prob runs in two passes so that the Bessel code (double arithmetic, one evaluation per ROW) never idles the
+// lanes that stream the rows: pass 1 is elementwise over kappa (log C_m, or -g A_m for the backward), pass 2 uses the
+// sampler's row mapping (LPR lanes x 4 elements, DPP reduction) for <mu, x> and adds kappa <mu, x>.
 template <typename T, bool BWD>
-__global__ __launch_bounds__(256) void vmf_log_prob_kernel(const T* __restrict__ mu, int64_t mu_stride,
-                                                           const T* __restrict__ kappa, int64_t kappa_stride,
-                                                           const T* __restrict__ x, const T* __restrict__ gl,
-                                                           T* __restrict__ logp, T* __restrict__ dmu,
-                                                           T* __restrict__ dx, T* __restrict__ dkappa, int64_t n,
-                                                           int m, VmfDim dim) {
+__global__ __launch_bounds__(256) void vmf_log_prob_rowterm_kernel(const T* __restrict__ kappa, int64_t kappa_stride,
+                                                                    const T* __restrict__ gl, T* __restrict__ out,
+                                                                    int64_t n, VmfDim dim) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double k = (double)kappa[i * kappa_stride];
+    if (!BWD) out[i] = (T)vmf_log_norm(dim, k);
+    else out[i] = (T)(-(double)gl[i] * vmf_mean_resultant(dim, k));  // d log C_m / dk = -A_m(k)
+  }
+}
+
+template <typename T>
+struct LogProbParams {
+  const T* mu; const T* kappa; const T* x; const T* gl;
+  T* logp; T* dmu; T* dx; T* dkappa;
+  int64_t n; int64_t mu_stride; int kappa_stride, m;
+};
+
+template <typename T, int LPR, int P, bool VEC, bool BWD>
+__global__ __launch_bounds__(WAVES * 64) void vmf_log_prob_dot_kernel(LogProbParams<T> p) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  for (int64_t row = wave_id; row < n; row += n_waves) {
-    const T* mrow = mu + row * mu_stride;
-    const T* xrow = x + row * (int64_t)m;
-    const T k = kappa[row * kappa_stride];
+  constexpr int RPI = 64 / LPR;
+  const int sub = lane % LPR, grp = lane / LPR;
+  const int m = p.m;
+  const int64_t n_steps = (p.n + RPI - 1) / RPI;
+  const int64_t wave_id = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  const int64_t step_end = (wave_id + 1) * BWD_STEPS < n_steps ? (wave_id + 1) * BWD_STEPS : n_steps;
+  for (int64_t step = wave_id * BWD_STEPS; step < step_end; ++step) {  // wave-uniform
+    const int64_t r = step * RPI + grp;
+    const bool valid = r < p.n;
+    const int64_t row = valid ? r : 0;
+    const T* mrow = p.mu + row * p.mu_stride;
+    const T* xrow = p.x + row * (int64_t)m;
+    T mu[P][4], x[P][4];
     T dot = 0;
-    for (int c = lane; c < m; c += 64) dot += mrow[c] * xrow[c];
-    dot = group_allreduce_sum<64, T>(dot);
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const int chunk = j * LPR + sub;
+      load4<T, VEC>(mrow, 4 * chunk, m, mu[j]);
+      load4<T, VEC>(xrow, 4 * chunk, m, x[j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dot += mu[j][i] * x[j][i];
+    }
+    dot = group_allreduce_sum<LPR, T>(dot);
+    if (!valid) continue;
+    const T k = p.kappa[row * p.kappa_stride];
     if (!BWD) {
-      if (lane == 0) logp[row] = (T)((double)k * (double)dot + vmf_log_norm(dim, (double)k));
+      if (sub == 0) p.logp[row] += k * dot;  // log C_m(kappa) was stored by pass 1
     } else {
-      const T g = gl[row];
-      for (int c = lane; c < m; c += 64) {
-        if (dmu) dmu[row * (int64_t)m + c] = g * k * xrow[c];
-        if (dx) dx[row * (int64_t)m + c] = g * k * mrow[c];
+      const T gk = p.gl[row] * k;
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const int chunk = j * LPR + sub;
+        T a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = gk * x[j][i]; b[i] = gk * mu[j][i]; }
+        if (p.dmu) store4<T, VEC>(p.dmu + row * (int64_t)m, 4 * chunk, m, a);
+        if (p.dx) store4<T, VEC>(p.dx + row * (int64_t)m, 4 * chunk, m, b);
       }
-      // d log C_m / dk = -A_m(k)
-      if (dkappa && lane == 0) dkappa[row] = (T)((double)g * ((double)dot - vmf_mean_resultant(dim, (double)k)));
+      if (p.dkappa && sub == 0) p.dkappa[row] += p.gl[row] * dot;  // -g A_m(kappa) was stored by pass 1
     }
   }
+}
+
+template <typename T, bool VEC, bool BWD>
+static void launch_log_prob(const LogProbParams<T>& p, int grid, hipStream_t s) {
+  const int chunks = (p.m + 3) / 4;
+#define VMF_CALL(L, PP) \
+  hipLaunchKernelGGL((vmf_log_prob_dot_kernel<T, L, PP, VEC, BWD>), dim3(grid), dim3(WAVES * 64), 0, s, p)
+  VMF_SHAPE_SWITCH(chunks, VMF_CALL);
+#undef VMF_CALL
+}
+
+template <typename T, bool BWD>
+static int log_prob_t(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, const void* x,
+                      const void* gl, void* logp, void* dmu, void* dx, void* dkappa, int64_t n, int m, hipStream_t s) {
+  LogProbParams<T> p = {};
+  p.mu = (const T*)mu; p.kappa = (const T*)kappa; p.x = (const T*)x; p.gl = (const T*)gl;
+  p.logp = (T*)logp; p.dmu = (T*)dmu; p.dx = (T*)dx; p.dkappa = (T*)dkappa;
+  p.n = n; p.mu_stride = mu_stride; p.kappa_stride = (int)kappa_stride; p.m = m;
+  VmfDim dim = make_vmf_dim(m);
+  T* rowterm = BWD ? (T*)dkappa : (T*)logp;
+  if (rowterm)
+    hipLaunchKernelGGL((vmf_log_prob_rowterm_kernel<T, BWD>), dim3(vmf_grid_for(n, 256)), dim3(256), 0, s, (const T*)kappa,
+                       kappa_stride, (const T*)gl, rowterm, n, dim);
+  const bool vec = (m % 4 == 0) && (mu_stride % 4 == 0) && aligned16(mu) && aligned16(x) && (!dmu || aligned16(dmu)) &&
+                   (!dx || aligned16(dx));
+  const int chunks = (m + 3) / 4;
+  int lpr = 1;
+  while (lpr < chunks && lpr < 64) lpr *= 2;
+  const int64_t steps = (n + (64 / lpr) - 1) / (64 / lpr);
+  const int64_t waves = (steps + BWD_STEPS - 1) / BWD_STEPS;
+  int64_t gb = (waves + WAVES - 1) / WAVES;
+  VMF_REQUIRE(gb <= 0x7fffffff, VMF_ERR_UNSUPPORTED, "n=%lld rows need more than 2^31 workgroups", (long long)n);
+  const int grid = (int)(gb < 1 ? 1 : gb);
+  if (vec) launch_log_prob<T, true, BWD>(p, grid, s);
+  else launch_log_prob<T, false, BWD>(p, grid, s);
+  return VMF_OK;
 }
 
 extern "C" int vmf_log_prob_fwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride,
                                 const void* x, void* logp, int64_t n, int m, int dtype, vmf_stream_t stream) {
   VMF_REQUIRE(n >= 0 && m >= 2, VMF_ERR_BAD_ARG, "bad n/m");
+  VMF_REQUIRE(m <= 2048, VMF_ERR_UNSUPPORTED, "m=%d > 2048 is not supported", m);
   VMF_REQUIRE(kappa_stride == 0 || kappa_stride == 1, VMF_ERR_BAD_ARG, "kappa_stride must be 0 or 1");
   VMF_REQUIRE(mu_stride == 0 || mu_stride >= m, VMF_ERR_BAD_ARG, "mu_stride=%lld", (long long)mu_stride);
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(mu && kappa && x && logp, VMF_ERR_BAD_ARG, "vmf_log_prob_fwd: null pointer");
-  VmfDim dim = make_vmf_dim(m);
-  int grid = vmf_grid_for(n, 4);
-  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((vmf_log_prob_kernel<T, false>), dim3(grid), dim3(256), 0,
-                                               (hipStream_t)stream, (const T*)mu, mu_stride, (const T*)kappa,
-                                               kappa_stride, (const T*)x, (const T*)nullptr, (T*)logp, (T*)nullptr,
-                                               (T*)nullptr, (T*)nullptr, n, m, dim));
+  int rc;
+  VMF_DISPATCH_DTYPE(dtype, rc = log_prob_t<T, false>(mu, mu_stride, kappa, kappa_stride, x, nullptr, logp, nullptr,
+                                                      nullptr, nullptr, n, m, (hipStream_t)stream));
+  if (rc) return rc;
   return vmf_check_launch("vmf_log_prob_fwd");
 }
 
@@ -593,16 +671,15 @@ extern "C" int vmf_log_prob_bwd(const void* mu, int64_t mu_stride, const void* k
                                 const void* x, const void* gl, void* dmu, void* dx, void* dkappa, int64_t n, int m,
                                 int dtype, vmf_stream_t stream) {
   VMF_REQUIRE(n >= 0 && m >= 2, VMF_ERR_BAD_ARG, "bad n/m");
+  VMF_REQUIRE(m <= 2048, VMF_ERR_UNSUPPORTED, "m=%d > 2048 is not supported", m);
   VMF_REQUIRE(kappa_stride == 0 || kappa_stride == 1, VMF_ERR_BAD_ARG, "kappa_stride must be 0 or 1");
   VMF_REQUIRE(mu_stride == 0 || mu_stride >= m, VMF_ERR_BAD_ARG, "mu_stride=%lld", (long long)mu_stride);
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(mu && kappa && x && gl, VMF_ERR_BAD_ARG, "vmf_log_prob_bwd: null pointer");
-  VmfDim dim = make_vmf_dim(m);
-  int grid = vmf_grid_for(n, 4);
-  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((vmf_log_prob_kernel<T, true>), dim3(grid), dim3(256), 0,
-                                               (hipStream_t)stream, (const T*)mu, mu_stride, (const T*)kappa,
-                                               kappa_stride, (const T*)x, (const T*)gl, (T*)nullptr, (T*)dmu,
-                                               (T*)dx, (T*)dkappa, n, m, dim));
+  int rc;
+  VMF_DISPATCH_DTYPE(dtype, rc = log_prob_t<T, true>(mu, mu_stride, kappa, kappa_stride, x, gl, nullptr, dmu, dx, dkappa,
+                                                     n, m, (hipStream_t)stream));
+  if (rc) return rc;
   return vmf_check_launch("vmf_log_prob_bwd");
 }
 

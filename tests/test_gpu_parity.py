@@ -406,7 +406,7 @@ def test_general_rsample_distribution_ks():
     """KS test of w = <z, mu> on freshly drawn samples against the exact marginal"""
     import scipy.integrate
     import scipy.stats as st
-    for m, kappa in ((64, 50.0), (512, 2000.0), (3, 4.0), (10, 0.3)):
+    for m, kappa in ((64, 50.0), (512, 2000.0), (3, 4.0), (10, 0.3), (2, 2.5), (64, 9000.0)):
         n = 200000
         mu = torch.zeros(1, m, device=DEV)
         mu[0, 1] = 1.0
@@ -424,8 +424,9 @@ def test_general_rsample_distribution_ks():
 
 
 def test_general_rsample_full_size_properties():
-    """m = 64 at 2^22 rows (size-independent properties): unit norm, <z,mu> = w, shard-invariance of the tail rows"""
-    n, m = 1 << 22, 64
+    """BASELINE configs[2] at full size, m = 64 and 2^24 rows, through size-independent properties: unit norm,
+    <z,mu> = w, E[w] = A_m(kappa), shard-invariance of the tail rows"""
+    n, m = 1 << 24, 64
     g = torch.Generator(device=DEV).manual_seed(1)
     mu = torch.nn.functional.normalize(torch.randn(n, m, device=DEV, generator=g), dim=-1)
     kappa = torch.exp(torch.rand(n, device=DEV, generator=g) * np.log(1e4))
@@ -449,6 +450,108 @@ def test_general_rsample_full_size_properties():
                                     1000, m, None, None, 0, None, 64, a, 99, 0, _lib.VMF_F32, _lib.stream_ptr(DEV))
     _lib.check(rc, "vmf_rsample_fwd")
     assert torch.equal(z2, z[a:])
+
+
+def test_high_dim_regime_full_size_properties():
+    """BASELINE configs[3]: m = 512, kappa up to 1e5, 2^22 rows; the log-normaliser runs on the asymptotic branch and
+    the fused log_prob must agree with the separate kernel"""
+    n, m = 1 << 22, 512
+    g = torch.Generator(device=DEV).manual_seed(2)
+    mu = torch.empty(n, m, device=DEV)
+    for s0 in range(0, n, 1 << 19):
+        mu[s0:s0 + (1 << 19)] = torch.nn.functional.normalize(
+            torch.randn(min(1 << 19, n - s0), m, device=DEV, generator=g), dim=-1)
+    kappa = torch.exp(torch.rand(n, device=DEV, generator=g) * np.log(1e5))
+    q = VonMisesFisher(mu, kappa, validate_args=False, generator=rng.PhiloxGenerator(11, 0))
+    z, lp = q.rsample(return_log_prob=True)
+    assert float((z.norm(dim=-1) - 1).abs().max()) < 2e-4
+    sel = slice(0, 1 << 16)
+    lp2 = VonMisesFisher(mu[sel].double(), kappa[sel].double(), validate_args=False).log_prob(z[sel].double())
+    rel = ((lp[sel].double() - lp2).abs() / (lp2.abs() + 1.0)).max()
+    assert float(rel) < 2e-4, float(rel)
+    band = (kappa > 900) & (kappa < 1100)
+    A = float(bessel_ratio(256.0, torch.tensor([1000.0], device=DEV, dtype=torch.float64)))
+    assert abs(float((z[band] * mu[band]).sum(-1).mean()) - A) < 5e-3
+
+
+def test_product_of_circles_and_s1_sampler_large():
+    """BASELINE configs[4] on one GPU at reduced row count (the full 2^26 x 16 circles is the 8-GPU case): a product
+    of 16 von Mises circles per row = 16 independent m = 2 rows, plus the S^1 projected-normal sampler and the
+    I1/I0 KL on the same kappa"""
+    import scipy.stats as st
+    rows, circles = 1 << 18, 16
+    n = rows * circles
+    g = torch.Generator(device=DEV).manual_seed(3)
+    ang = torch.rand(n, device=DEV, generator=g) * 2 * np.pi
+    mu = torch.stack([ang.cos(), ang.sin()], dim=-1)
+    kappa = torch.exp(torch.rand(n, device=DEV, generator=g) * np.log(1e3))
+    z = VonMisesFisher(mu, kappa, validate_args=False).rsample().view(rows, circles, 2)
+    assert float((z.norm(dim=-1) - 1).abs().max()) < 1e-5
+    # angle offsets follow the von Mises law: check one narrow kappa band with a KS test
+    band = ((kappa > 4.9) & (kappa < 5.1)).view(rows, circles)
+    d = z[band].double()
+    m2 = mu.view(rows, circles, 2)[band].double()
+    theta = torch.atan2(m2[:, 0] * d[:, 1] - m2[:, 1] * d[:, 0], (m2 * d).sum(-1)).cpu().numpy()
+    assert st.kstest(theta[:20000], st.vonmises(5.0).cdf).pvalue > 1e-3
+    # S^1 projected normal + KL (philox noise), unit norm and finite loss
+    os.environ["VMF_RNG"] = "philox"
+    try:
+        zz = s1_reparameterize(mu, kappa[:, None])
+    finally:
+        os.environ.pop("VMF_RNG")
+    assert float((zz.norm(dim=-1) - 1).abs().max()) < 1e-5
+    assert float((zz * mu).sum(-1).mean()) > 0.9
+    klv = klmod.kl_sum(kappa, "stable_m2") / n
+    assert torch.isfinite(klv) and float(klv) > 0
+
+
+def test_spherical_vae_train_step_batch128():
+    """BASELINE configs[1] with the reference-exact latent (m = 3): 28x28 synthetic inputs, batch 128, forward +
+    _elbo + backward + Adam step.  The same step is restated with torch ops following
+    sampler/von_mises_fisher.py:30,58-84 and model/spherical_vae.py:141-184 and fed the same torch noise."""
+    os.environ["VMF_RNG"] = "torch"
+    cfg = dict(extrinsic_dim=784, latent_dim=3, sftbeta=1.0, encoder_width=128, encoder_depth=4, decoder_width=128,
+               decoder_depth=4, dropout_p=0.1, device="cuda", gamma=1.0, beta=0.01)
+    torch.manual_seed(0)
+    model = SphericalVAE(cfg)
+    ref = SphericalVAE(cfg)
+    ref.load_state_dict(model.state_dict())
+    x = torch.rand(128, 784, device=DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    torch.manual_seed(42)
+    z, x_mu, params = model(x)
+    assert z.shape == (128, 128, 3) and x_mu.shape == (128, 128, 784)
+    loss = model._elbo(x, x_mu, params)
+    opt.zero_grad()
+    loss.backward()
+
+    # torch restatement on the same device with the same noise
+    torch.manual_seed(42)
+    z_mu, z_kappa = ref.encode(x)
+    loc = z_mu / (z_mu.norm(dim=-1, keepdim=True) + 1e-5)
+    u = torch.rand(z_kappa.shape, device=DEV)
+    eps = torch.randn(z_mu.shape, device=DEV)
+    w = 1 + torch.logsumexp(torch.stack([u.log(), (1 - u).log() - 2 * z_kappa], 0), 0) / z_kappa
+    v = eps - (eps * loc).sum(-1, keepdim=True) * loc
+    v = v / (v.norm(dim=-1, keepdim=True) + 1e-8)
+    we = w.unsqueeze(-1)
+    z_ref = we * loc + torch.sqrt(torch.clamp(1 - we ** 2, 1e-10, 1.0)) * v
+    x_mu_ref = ref.decode(z_ref)
+    k = torch.clamp(z_kappa, min=1e-8)
+    kl = torch.where(k > 20, k.log() - (k - np.log(2.0)) + k * (1 + 2 * torch.exp(-2 * k)) - 1,
+                     k.log() - torch.log(torch.sinh(k) + 1e-8) + k * torch.cosh(k) / (torch.sinh(k) + 1e-8) - 1)
+    loss_ref = cfg["gamma"] * torch.mean((x - x_mu_ref) ** 2) + cfg["beta"] * kl.mean()
+    loss_ref.backward()
+    np.testing.assert_allclose(N(z), N(z_ref), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(float(loss), float(loss_ref), rtol=1e-5)
+    for (name, a), (_, b) in zip(model.named_parameters(), ref.named_parameters()):
+        scale = float(b.grad.abs().max()) + 1e-12
+        np.testing.assert_allclose(N(a.grad), N(b.grad), rtol=2e-3, atol=2e-3 * scale, err_msg=name)
+    before = [p.detach().clone() for p in model.parameters()]
+    opt.step()
+    assert any(not torch.equal(a, b) for a, b in zip(before, model.parameters()))
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+    os.environ.pop("VMF_RNG")
 
 
 @pytest.mark.parametrize("m", [3, 10, 64, 512])

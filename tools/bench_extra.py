@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Secondary measurements on one MI355X (not the headline metric): per-kernel time and algorithmic GB/s for the other
+configurations of the path.  Prints a markdown table; run on the GPU box:  python tools/bench_extra.py"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from medicalimageanalysis_amd import _lib, kl as klmod, rng  # noqa: E402
+from medicalimageanalysis_amd.sampler.ive import ive  # noqa: E402
+from medicalimageanalysis_amd.sampler.von_mises_fisher import VonMisesFisher, VonMisesFisher3D  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def timeit(fn, reps=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in ev]))
+
+
+def row(name, ms, nbytes, units, unit_name):
+    print(f"| {name} | {ms:.3f} | {nbytes / ms / 1e6:.0f} | {units / ms / 1e6:.2f} G {unit_name}/s |")
+
+
+def main():
+    lib = _lib.lib()
+    sp = _lib.stream_ptr(DEV)
+    print("| case | ms | algorithmic GB/s | rate |")
+    print("|---|---|---|---|")
+    g = torch.Generator(device=DEV).manual_seed(0)
+
+    # --- general m forward: m = 64 with fused log_prob, m = 512, m = 10 (S^9), fp64 m = 64
+    for m, n, dt, logp in ((64, 1 << 24, torch.float32, True), (512, 1 << 22, torch.float32, False),
+                           (10, 1 << 24, torch.float32, False), (64, 1 << 22, torch.float64, False),
+                           (2, 1 << 24, torch.float32, False)):
+        mu = torch.nn.functional.normalize(torch.randn(n, m, device=DEV, generator=g, dtype=torch.float32), dim=-1).to(dt)
+        kap = torch.exp(torch.rand(n, device=DEV, generator=g) * np.log(1e4)).to(dt)
+        z = torch.empty_like(mu)
+        lp = torch.empty(n, device=DEV, dtype=dt) if logp else None
+        es = 4 if dt == torch.float32 else 8
+
+        def f():
+            rc = lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(z), None, None, None, _lib.ptr(lp), n, m,
+                                     None, None, 0, None, 64, 0, 1, 0, _lib.dtype_code(mu), sp)
+            assert rc == 0
+        ms = timeit(f)
+        row(f"rsample fwd m={m} n=2^{int(np.log2(n))} {str(dt)[6:]}" + (" + fused log_prob" if logp else ""), ms,
+            n * (2 * m + 1 + (1 if logp else 0)) * es, n, "rows")
+        if m == 64 and dt == torch.float32:
+            w = torch.empty(n, device=DEV)
+            omw = torch.empty(n, device=DEV)
+            lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(z), _lib.ptr(w), _lib.ptr(omw), None, None, n, m,
+                                None, None, 0, None, 64, 0, 1, 0, _lib.VMF_F32, sp)
+            gz = torch.randn_like(mu)
+            dmu = torch.empty_like(mu)
+            dk = torch.empty(n, device=DEV)
+
+            def fb():
+                rc = lib.vmf_rsample_bwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(w), _lib.ptr(omw), _lib.ptr(gz), None,
+                                         _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 1, 0, _lib.VMF_F32, sp)
+                assert rc == 0
+            ms = timeit(fb)
+            row("rsample bwd m=64 n=2^24 float32 (noise regenerated)", ms, n * (3 * m + 3) * 4, n, "rows")
+            q = VonMisesFisher(mu, kap, validate_args=False)
+            ms = timeit(lambda: q.log_prob(z))
+            row("log_prob m=64 n=2^24 float32", ms, n * (2 * m + 2) * 4, n, "rows")
+            del gz, dmu
+        del mu, z
+        torch.cuda.empty_cache()
+
+    # --- m = 3 reference-exact path
+    for n in (4096, 1 << 24):
+        loc = torch.randn(n, 3, device=DEV, generator=g)
+        kap = torch.rand(n, device=DEV, generator=g) * 99 + 1
+        q = VonMisesFisher3D(loc, kap, validate_args=False)
+        os.environ["VMF_RNG"] = "philox"
+        ms = timeit(lambda: q.rsample())
+        row(f"VonMisesFisher3D.rsample B={n} fp32, in-kernel noise (incl. python)", ms, n * 28, n, "rows")
+        os.environ["VMF_RNG"] = "torch"
+        ms = timeit(lambda: q.rsample())
+        row(f"VonMisesFisher3D.rsample B={n} fp32, torch noise in reference order", ms, n * 44, n, "rows")
+        ms = timeit(lambda: klmod.kl_mean(kap, "spherical"))
+        row(f"KL mean (spherical piecewise) n={n} fp32", ms, n * 4, n, "elems")
+    loc = torch.randn(128, 3, device=DEV, generator=g)
+    kap = torch.rand(128, 1, device=DEV, generator=g) * 99 + 1
+    q = VonMisesFisher3D(loc, kap, validate_args=False)
+    ms = timeit(lambda: q.rsample())
+    row("VonMisesFisher3D.rsample B=128 scale (B,1) -> (128,128,3)", ms, 128 * 128 * 12, 128 * 128, "rows")
+
+    # --- ive
+    n = 1 << 24
+    x = torch.exp(torch.rand(n, device=DEV, generator=g, dtype=torch.float64) * np.log(1e5))
+    for v in (0.5, 31.0, 255.0):
+        ms = timeit(lambda: ive(v, x), reps=5, warm=1)
+        row(f"ive({v}, z) n=2^24 fp64 forward", ms, n * 16, n, "evals")
+    xr = x.clone().requires_grad_()
+    y = ive(31.0, xr)
+
+    def fbw():
+        xr.grad = None
+        y.backward(torch.ones_like(y), retain_graph=True)
+    ms = timeit(fbw, reps=5, warm=1)
+    row("ive(31, z) n=2^24 fp64 backward", ms, n * 24, n, "evals")
+
+
+if __name__ == "__main__":
+    main()
