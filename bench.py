@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--rows", type=int, default=1 << 24, help="rows per GPU")
     ap.add_argument("--m", type=int, default=64)
     ap.add_argument("--log-prob", action="store_true", help="also write the fused log p(z) (520 B/row)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                    "the multi-rank code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-rows", type=int, default=1 << 22, help="rows of the CPU-baseline sample (0: skip)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="optional file with {'hbm_bytes_per_launch': ...} from a rocprofv3 --pmc pass")
@@ -82,7 +84,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
     if a.gpus != world and rank == 0:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 

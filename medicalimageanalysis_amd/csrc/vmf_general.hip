@@ -125,8 +125,10 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
+// Second launch bound = waves per SIMD: the fp32 streaming shapes fit 8 waves (<= 64 VGPRs) without spilling once the
+// compiler is told to; the other instantiations keep the default.
 template <typename T, int LPR, int P, int MODE>
-__global__ __launch_bounds__(WAVES * 64) void vmf_rsample_fwd_kernel(FwdParams<T> p) {
+__global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2) ? 8 : 1) void vmf_rsample_fwd_kernel(FwdParams<T> p) {
   constexpr bool VEC = MODE >= 1;
   constexpr bool FAST = MODE == 2;
   __shared__ T s_w[WAVES][TILE_ROWS];
