@@ -346,7 +346,7 @@ def _call_rsample_pre(mu, kappa, pe, pu, ga, dtype):
 
 @pytest.mark.parametrize("tag", ["f64", "f32"])
 @pytest.mark.parametrize("m,n", [(3, 1000), (10, 257), (64, 5000), (130, 300), (512, 700), (1024, 65), (2, 100),
-                                 (64, 1)])
+                                 (64, 1), (2048, 33), (2047, 9), (5, 129), (256, 128)])
 def test_general_rsample_predrawn_accept_index_bit_exact(oracle, tag, m, n):
     gen = np.random.default_rng(100 + m)
     dt = np.float64 if tag == "f64" else np.float32
@@ -647,6 +647,37 @@ def test_general_log_prob_entropy_kl(oracle, tag, m):
         A = oracle.bessel_ratio(m / 2, kappa)
         np.testing.assert_allclose(N(tk.grad), (mu * x).sum(1) - A, rtol=1e-8, atol=1e-9)
         np.testing.assert_allclose(N(tm.grad), kappa[:, None] * x, rtol=1e-12)
+
+
+def test_general_shared_parameters_and_shapes():
+    """one (mu, kappa) shared by all samples (stride-0 rows), scale given as (..., 1), batch x sample expansion, and the
+    gradient reduction over the shared row"""
+    m = 64
+    mu = torch.nn.functional.normalize(torch.randn(1, m, device=DEV, dtype=torch.float64), dim=-1).requires_grad_()
+    kappa = torch.tensor([[30.0]], device=DEV, dtype=torch.float64, requires_grad=True)
+    g = rng.PhiloxGenerator(21, 0)
+    q = VonMisesFisher(mu, kappa, validate_args=False, generator=g)
+    z = q.rsample(torch.Size([1000]))
+    assert z.shape == (1000, 1, m)
+    c = torch.randn_like(z)
+    (z * c).sum().backward()
+    # the same draw through explicitly replicated rows (row r of the shared call == row r here)
+    mu2 = mu.detach().expand(1000, m).contiguous().requires_grad_()
+    k2 = kappa.detach().reshape(1).expand(1000).contiguous().requires_grad_()
+    z2 = VonMisesFisher(mu2, k2, validate_args=False, generator=rng.PhiloxGenerator(21, 0)).rsample()
+    assert torch.equal(z2, z[:, 0, :])
+    (z2 * c[:, 0, :]).sum().backward()
+    np.testing.assert_allclose(N(mu.grad), N(mu2.grad.sum(0, keepdim=True)), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(N(kappa.grad).reshape(-1), N(k2.grad.sum(0, keepdim=True)), rtol=1e-10, atol=1e-12)
+    # batch (3, 5) with sample shape (2,)
+    mu3 = torch.nn.functional.normalize(torch.randn(3, 5, m, device=DEV), dim=-1)
+    k3 = torch.rand(3, 5, 1, device=DEV) * 100 + 1
+    q3 = VonMisesFisher(mu3, k3, validate_args=False)
+    z3 = q3.rsample(torch.Size([2]))
+    assert z3.shape == (2, 3, 5, m) and q3.log_prob(z3).shape == (2, 3, 5)
+    assert q3.entropy().shape == (3, 5) and q3.mean.shape == (3, 5, m)
+    assert float((z3.norm(dim=-1) - 1).abs().max()) < 1e-5
+    assert VonMisesFisher(mu3[:0], k3[:0], validate_args=False).rsample().shape == (0, 5, m)
 
 
 def test_general_fused_log_prob_matches_separate_call():
