@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): vMF rsample, m = 64, fp32,
+Workload (the configuration the headline metric is quoted on): vMF rsample, m = 64, fp32,
 2^24 rows PER GPU, one (mu_i, kappa_i) per row, mu = normalize(randn), kappa = exp(U[0, ln 1e4]), noise from the
 in-kernel Philox streams keyed by the GLOBAL row index (rank r owns rows [r 2^24, (r+1) 2^24)): weak scaling, no
 data-path collective.  A step is one pass of `vmf_rsample_fwd` (C ABI of libvmf_hip.so) over the rank's rows with

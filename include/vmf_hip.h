@@ -3,7 +3,7 @@
  *
  * The reference is pure Python; the binding a maintainer adds is a ctypes stub in each of
  * sampler/von_mises_fisher.py, sampler/ive.py, sampler/spherical_uniform.py, model/spherical_vae.py,
- * model/torus_vae.py (shown in INTEGRATION.md).  Every entry point below names the reference lines whose
+ * model/torus_vae.py.  Every entry point below names the reference lines whose
  * arithmetic it replaces.
  *
  * Conventions

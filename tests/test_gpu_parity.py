@@ -424,7 +424,7 @@ def test_general_rsample_distribution_ks():
 
 
 def test_general_rsample_full_size_properties():
-    """BASELINE configs[2] at full size, m = 64 and 2^24 rows, through size-independent properties: unit norm,
+    """the headline configuration at full size, m = 64 and 2^24 rows, through size-independent properties: unit norm,
     <z,mu> = w, E[w] = A_m(kappa), shard-invariance of the tail rows"""
     n, m = 1 << 24, 64
     g = torch.Generator(device=DEV).manual_seed(1)
@@ -453,7 +453,7 @@ def test_general_rsample_full_size_properties():
 
 
 def test_high_dim_regime_full_size_properties():
-    """BASELINE configs[3]: m = 512, kappa up to 1e5, 2^22 rows; the log-normaliser runs on the asymptotic branch and
+    """the high-dimension configuration: m = 512, kappa up to 1e5, 2^22 rows; the log-normaliser runs on the asymptotic branch and
     the fused log_prob must agree with the separate kernel"""
     n, m = 1 << 22, 512
     g = torch.Generator(device=DEV).manual_seed(2)
@@ -475,7 +475,7 @@ def test_high_dim_regime_full_size_properties():
 
 
 def test_product_of_circles_and_s1_sampler_large():
-    """BASELINE configs[4] on one GPU at reduced row count (the full 2^26 x 16 circles is the 8-GPU case): a product
+    """the product-of-circles configuration on one GPU at reduced row count (2^26 x 16 circles is the 8-GPU case): a product
     of 16 von Mises circles per row = 16 independent m = 2 rows, plus the S^1 projected-normal sampler and the
     I1/I0 KL on the same kappa"""
     import scipy.stats as st
@@ -506,7 +506,7 @@ def test_product_of_circles_and_s1_sampler_large():
 
 
 def test_spherical_vae_train_step_batch128():
-    """BASELINE configs[1] with the reference-exact latent (m = 3): 28x28 synthetic inputs, batch 128, forward +
+    """the Spherical-VAE train-step configuration with the reference-exact latent (m = 3): 28x28 synthetic inputs, batch 128, forward +
     _elbo + backward + Adam step.  The same step is restated with torch ops following
     sampler/von_mises_fisher.py:30,58-84 and model/spherical_vae.py:141-184 and fed the same torch noise."""
     os.environ["VMF_RNG"] = "torch"
