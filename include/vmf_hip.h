@@ -87,6 +87,11 @@ int vmf3_rsample_bwd(const void* loc, const void* scale, const void* u, const vo
 int vmf3_log_prob_ref(const void* loc, const void* scale, const void* x, void* logp, void* lognorm, int64_t n,
                       int dtype, vmf_stream_t stream);
 
+/* Backward of vmf3_log_prob_ref (what autograd derives from CNN_experiment/von_mises_fisher.py:92-108): gl = dL/dlogp;
+ * dloc (n,3), dscale (n), dx (n,3) nullable. */
+int vmf3_log_prob_ref_bwd(const void* loc, const void* scale, const void* x, const void* gl, void* dloc, void* dscale,
+                          void* dx, int64_t n, int dtype, vmf_stream_t stream);
+
 /* VonMisesFisher3D.mean (sampler/von_mises_fisher.py:38-43): l * ive(3/2,k)/ive(1/2,k) */
 int vmf3_mean(const void* loc, const void* scale, void* mean, int64_t n, int dtype, vmf_stream_t stream);
 

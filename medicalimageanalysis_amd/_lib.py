@@ -25,6 +25,7 @@ _PROTOS = {
     "vmf3_rsample_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I64P, _I64P, _I64P, _I64P, _I64P, _I, _U64,
                          _U64, _P],
     "vmf3_log_prob_ref": [_P, _P, _P, _P, _P, _I64, _I, _P],
+    "vmf3_log_prob_ref_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _P],
     "vmf3_mean": [_P, _P, _P, _I64, _I, _P],
     "vmf_ive_fwd": [_D, _P, _P, _I64, _I, _P],
     "vmf_ive_bwd": [_D, _P, _P, _P, _I64, _I, _P],

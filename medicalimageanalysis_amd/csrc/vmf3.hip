@@ -241,6 +241,50 @@ extern "C" int vmf3_log_prob_ref(const void* loc, const void* scale, const void*
   return vmf_check_launch("vmf3_log_prob_ref");
 }
 
+// backward of the above through loc, scale and x (what autograd derives from CNN_experiment/von_mises_fisher.py:92-108)
+template <typename T>
+__global__ __launch_bounds__(256) void vmf3_log_prob_ref_bwd_kernel(const T* __restrict__ loc,
+                                                                    const T* __restrict__ scale,
+                                                                    const T* __restrict__ x, const T* __restrict__ gl,
+                                                                    T* __restrict__ dloc, T* __restrict__ dscale,
+                                                                    T* __restrict__ dx, int64_t n) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const T k = scale[i], g = gl[i];
+    T r[3] = {loc[3 * i], loc[3 * i + 1], loc[3 * i + 2]};
+    T xv[3] = {x[3 * i], x[3 * i + 1], x[3 * i + 2]};
+    T l[3], nn;
+    v3_normalise_loc<T>(r, l, &nn);
+    const T dot = l[0] * xv[0] + l[1] * xv[1] + l[2] * xv[2];
+    if (dscale) {
+      // d/dk [k dot - (log k - log 4pi - log(sinh k + 1e-10))] = dot - 1/k + cosh k / (sinh k + 1e-10)
+      const T sh = M<T>::sinh(k) + (T)1e-10;
+      dscale[i] = g * (dot - (T)1 / k + M<T>::cosh(k) / sh);
+    }
+    if (dx) {
+      dx[3 * i] = g * k * l[0]; dx[3 * i + 1] = g * k * l[1]; dx[3 * i + 2] = g * k * l[2];
+    }
+    if (dloc) {
+      T dl[3] = {g * k * xv[0], g * k * xv[1], g * k * xv[2]};
+      const T nden = nn + (T)1e-5;
+      const T rdl = r[0] * dl[0] + r[1] * dl[1] + r[2] * dl[2];
+      for (int c = 0; c < 3; ++c) dloc[3 * i + c] = dl[c] / nden - r[c] * rdl / (nn * nden * nden);
+    }
+  }
+}
+
+extern "C" int vmf3_log_prob_ref_bwd(const void* loc, const void* scale, const void* x, const void* gl, void* dloc,
+                                     void* dscale, void* dx, int64_t n, int dtype, vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(loc && scale && x && gl, VMF_ERR_BAD_ARG, "vmf3_log_prob_ref_bwd: null pointer");
+  int grid = vmf_grid_for(n, 256);
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(vmf3_log_prob_ref_bwd_kernel<T>, dim3(grid), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)loc, (const T*)scale, (const T*)x,
+                                               (const T*)gl, (T*)dloc, (T*)dscale, (T*)dx, n));
+  return vmf_check_launch("vmf3_log_prob_ref_bwd");
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void vmf3_mean_kernel(const T* __restrict__ loc, const T* __restrict__ scale,
                                                         T* __restrict__ mean, int64_t n, BesselOrder o32,

@@ -192,31 +192,59 @@ class VonMisesFisher3D(Distribution):
         return out
 
 
+class _VMF3LogProbRef(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, loc, scale, x):
+        dev = _lib.require_hip(loc, scale, x)
+        locc, sc, xc = loc.detach().contiguous(), scale.detach().contiguous(), x.detach().contiguous()
+        logp = torch.empty_like(sc)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().vmf3_log_prob_ref(_lib.ptr(locc), _lib.ptr(sc), _lib.ptr(xc), _lib.ptr(logp), None, sc.numel(),
+                                              _lib.dtype_code(locc), _lib.stream_ptr(dev))
+        _lib.check(rc, "vmf3_log_prob_ref")
+        ctx.save_for_backward(locc, sc, xc)
+        return logp
+
+    @staticmethod
+    def backward(ctx, gl):
+        locc, sc, xc = ctx.saved_tensors
+        dev = locc.device
+        g = gl.to(locc.dtype).contiguous()
+        dloc, dscale, dx = torch.empty_like(locc), torch.empty_like(sc), torch.empty_like(xc)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().vmf3_log_prob_ref_bwd(_lib.ptr(locc), _lib.ptr(sc), _lib.ptr(xc), _lib.ptr(g), _lib.ptr(dloc),
+                                                  _lib.ptr(dscale), _lib.ptr(dx), sc.numel(), _lib.dtype_code(locc),
+                                                  _lib.stream_ptr(dev))
+        _lib.check(rc, "vmf3_log_prob_ref_bwd")
+        return dloc, dscale, dx
+
+
 class VonMisesFisher3DLogProb(VonMisesFisher3D):
     """The copy in CNN_experiment/von_mises_fisher.py, which adds log_prob / _log_normalization (:88-108) with the
-    reference's sign convention: log_prob = kappa <loc, x> - (log kappa - log 4 pi - log(sinh kappa + 1e-10))."""
-
-    def _launch(self, x):
-        loc = self._loc_raw.detach()
-        bshape = torch.broadcast_shapes(loc.shape[:-1], self.scale.shape, x.shape[:-1] if x is not None else ())
-        locb = loc.expand(bshape + (3,)).contiguous()
-        scaleb = self.scale.detach().to(loc.dtype).expand(bshape).contiguous()
-        xb = None if x is None else x.detach().to(loc.dtype).expand(bshape + (3,)).contiguous()
-        dev = _lib.require_hip(locb, scaleb, xb)
-        logp = None if x is None else torch.empty(bshape, device=dev, dtype=loc.dtype)
-        lognorm = torch.empty(bshape, device=dev, dtype=loc.dtype) if x is None else None
-        with torch.cuda.device(dev):
-            rc = _lib.lib().vmf3_log_prob_ref(_lib.ptr(locb), _lib.ptr(scaleb), _lib.ptr(xb), _lib.ptr(logp),
-                                              _lib.ptr(lognorm), scaleb.numel(), _lib.dtype_code(locb),
-                                              _lib.stream_ptr(dev))
-        _lib.check(rc, "vmf3_log_prob_ref")
-        return logp if x is not None else lognorm
+    reference's sign convention: log_prob = kappa <loc, x> - (log kappa - log 4 pi - log(sinh kappa + 1e-10)).
+    log_prob is differentiable in loc, scale and x, as it is in the reference."""
 
     def log_prob(self, x):
-        return self._launch(x)
+        loc = self._loc_raw
+        bshape = torch.broadcast_shapes(loc.shape[:-1], self.scale.shape, x.shape[:-1])
+        locb = loc.expand(bshape + (3,))
+        scaleb = self.scale.to(loc.dtype).expand(bshape)
+        xb = x.to(loc.dtype).expand(bshape + (3,))
+        if locb.numel() == 0:
+            return loc.new_empty(bshape)
+        return _VMF3LogProbRef.apply(locb, scaleb, xb)
 
     def _log_normalization(self):
-        return self._launch(None)
+        loc = self._loc_raw.detach()
+        bshape = torch.broadcast_shapes(loc.shape[:-1], self.scale.shape)
+        scaleb = self.scale.detach().to(loc.dtype).expand(bshape).contiguous()
+        dev = _lib.require_hip(scaleb)
+        lognorm = torch.empty(bshape, device=dev, dtype=loc.dtype)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().vmf3_log_prob_ref(None, _lib.ptr(scaleb), None, None, _lib.ptr(lognorm), scaleb.numel(),
+                                              _lib.dtype_code(scaleb), _lib.stream_ptr(dev))
+        _lib.check(rc, "vmf3_log_prob_ref")
+        return lognorm
 
 
 # ---- general m ---------------------------------------------------------------------------------------------

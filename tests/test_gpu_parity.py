@@ -192,6 +192,18 @@ def test_vmf3_log_prob_and_mean(golden, tag):
     fin = np.isfinite(ref) & keep
     close(lp[fin], ref[fin], tag)
     close(ln[fin], refn[fin], tag)
+    if tag == "f64":
+        # log_prob is differentiable like the reference's torch expression (CNN_experiment/von_mises_fisher.py:92-108)
+        sel = np.isfinite(ref) & (k < 300)
+        tl = T(g["loc_f64"][sel]).requires_grad_()
+        tk = T(g["scale_f64"][sel]).requires_grad_()
+        tx = T(g["x_f64"][sel]).requires_grad_()
+        VonMisesFisher3DLogProb(tl, tk, validate_args=False).log_prob(tx).sum().backward()
+        l2, k2, x2 = (t.detach().clone().requires_grad_() for t in (tl, tk, tx))
+        ln2 = l2 / (l2.norm(dim=-1, keepdim=True) + 1e-5)
+        (k2 * (ln2 * x2).sum(-1) - (torch.log(k2) - np.log(4 * np.pi) - torch.log(torch.sinh(k2) + 1e-10))).sum().backward()
+        for a, b in ((tl, l2), (tk, k2), (tx, x2)):
+            np.testing.assert_allclose(N(a.grad), N(b.grad), rtol=1e-10, atol=1e-12)
     gm = golden("g_mean")
     q = VonMisesFisher3D(T(gm[f"loc_{tag}"]), T(gm[f"scale_{tag}"]), validate_args=False)
     close(N(q.mean()), gm[f"mean_{tag}"], tag, atol32=1e-5)
@@ -798,6 +810,30 @@ def test_toroidal_vae_runs_and_matches_oracle_embedding(oracle, monkeypatch):
     loss = model._elbo(x, x_mu, (params[0], params[1])) + model._elbo(x, x_mu, (params[2], params[3]))
     loss.backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_hyperspherical_vae_s9_trains():
+    """latent S^9 (m = 10), 28x28 synthetic inputs, batch 128: a few Adam steps reduce the loss, gradients reach every
+    parameter"""
+    from medicalimageanalysis_amd.model.hyperspherical_vae import HypersphericalVAE
+    cfg = dict(extrinsic_dim=784, latent_dim=10, sftbeta=1.0, encoder_width=128, encoder_depth=2, decoder_width=128,
+               decoder_depth=2, dropout_p=0.1, device="cuda", gamma=1.0, beta=0.01)
+    torch.manual_seed(0)
+    model = HypersphericalVAE(cfg)
+    x = torch.rand(128, 784, device=DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    losses = []
+    for _ in range(30):
+        z, x_mu, params = model(x)
+        assert z.shape == (128, 10)
+        loss = model._elbo(x, x_mu, params)
+        opt.zero_grad()
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < 0.9 * losses[0], losses[::5]
+    np.testing.assert_allclose(N(z.norm(dim=-1)), 1.0, atol=1e-5)
 
 
 def test_error_conventions():
