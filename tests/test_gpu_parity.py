@@ -836,6 +836,39 @@ def test_hyperspherical_vae_s9_trains():
     np.testing.assert_allclose(N(z.norm(dim=-1)), 1.0, atol=1e-5)
 
 
+def test_entry_points_are_graph_capturable():
+    """the library neither allocates nor synchronises, so its launches can be captured into a HIP graph and replayed"""
+    loc = torch.randn(256, 3, device=DEV)
+    kap = torch.rand(256, device=DEV) * 50 + 1
+    u = torch.rand(256, device=DEV)
+    eps = torch.randn(256, 3, device=DEV)
+    mu = torch.nn.functional.normalize(torch.randn(512, 64, device=DEV), dim=-1)
+    k64 = torch.rand(512, device=DEV) * 100 + 1
+    q3 = VonMisesFisher3D(loc, kap, validate_args=False)
+    qm = VonMisesFisher(mu, k64, validate_args=False, generator=rng.PhiloxGenerator(5, 0))
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):  # warm-up outside capture
+        q3.rsample_with_noise(u, eps)
+        klmod.kl_mean(kap, "spherical")
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        z3 = q3.rsample_with_noise(u, eps)
+        klm = klmod.kl_mean(kap, "spherical")
+        zm = qm.rsample()
+    g.replay()
+    torch.cuda.synchronize()
+    ref3 = q3.rsample_with_noise(u, eps)
+    refm = VonMisesFisher(mu, k64, validate_args=False, generator=rng.PhiloxGenerator(5, 0)).rsample()
+    assert torch.equal(z3, ref3) and torch.equal(zm, refm)
+    assert abs(float(klm) - float(klmod.kl_mean(kap, "spherical"))) < 1e-6
+    u.copy_(torch.rand(256, device=DEV))  # new inputs in place, replay recomputes
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(z3, q3.rsample_with_noise(u, eps))
+
+
 def test_error_conventions():
     loc = torch.randn(4, 3, device=DEV)
     with pytest.raises(AssertionError):

@@ -100,6 +100,58 @@ def main():
     ms = timeit(lambda: q.rsample())
     row("VonMisesFisher3D.rsample B=128 scale (B,1) -> (128,128,3)", ms, 128 * 128 * 12, 128 * 128, "rows")
 
+    # --- Spherical-VAE train step, batch 128, 28x28 inputs, latent m = 3: this package vs the same step written with
+    #     torch ops following the reference's formulas (what the reference executes on a GPU)
+    from medicalimageanalysis_amd.model.spherical_vae import SphericalVAE
+    cfg = dict(extrinsic_dim=784, latent_dim=3, sftbeta=1.0, encoder_width=128, encoder_depth=4, decoder_width=128,
+               decoder_depth=4, dropout_p=0.1, device="cuda", gamma=1.0, beta=0.01)
+    torch.manual_seed(0)
+    model = SphericalVAE(cfg)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    x = torch.rand(128, 784, device=DEV)
+    torch.distributions.Distribution.set_default_validate_args(False)
+
+    def step_ours():
+        z, x_mu, params = model(x)
+        loss = model._elbo(x, x_mu, params)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+
+    def step_torch():
+        z_mu, z_kappa = model.encode(x)
+        loc = z_mu / (z_mu.norm(dim=-1, keepdim=True) + 1e-5)
+        u = torch.rand(z_kappa.shape, device=DEV)
+        w = 1 + torch.logsumexp(torch.stack([u.log(), (1 - u).log() - 2 * z_kappa], 0), 0) / z_kappa
+        eps = torch.randn(z_mu.shape, device=DEV)
+        v = eps - (eps * loc).sum(-1, keepdim=True) * loc
+        v = v / (v.norm(dim=-1, keepdim=True) + 1e-8)
+        we = w.unsqueeze(-1)
+        z = we * loc + torch.sqrt(torch.clamp(1 - we ** 2, 1e-10, 1.0)) * v
+        x_mu = model.decode(z)
+        loc2 = z_mu / (z_mu.norm(dim=-1, keepdim=True) + 1e-5)  # the second construction in _elbo  # noqa: F841
+        k = torch.clamp(z_kappa, min=1e-8)
+        small, large = k < 1e-3, k > 20.0
+        mid = ~(small | large)
+        kl = torch.zeros_like(k)
+        if mid.any():
+            km = k[mid]
+            sh = torch.sinh(km) + 1e-8
+            kl[mid] = torch.log(km) - torch.log(sh) + km * (torch.cosh(km) / sh) - 1.0
+        if large.any():
+            kL = k[large]
+            kl[large] = torch.log(kL) - (kL - np.log(2.0)) + kL * (1.0 + 2.0 * torch.exp(-2.0 * kL)) - 1.0
+        loss = cfg["gamma"] * torch.mean((x - x_mu) * (x - x_mu)) + cfg["beta"] * kl.mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+
+    os.environ["VMF_RNG"] = "torch"
+    ms_a = timeit(step_ours, reps=30, warm=5)
+    ms_b = timeit(step_torch, reps=30, warm=5)
+    print(f"| SphericalVAE train step B=128 (z 128x128x3): this package | {ms_a:.3f} | - | {1e3 / ms_a:.0f} steps/s |")
+    print(f"| same step with the sampler/KL as torch ops (reference formulas) | {ms_b:.3f} | - | {1e3 / ms_b:.0f} steps/s |")
+
     # --- ive
     n = 1 << 24
     x = torch.exp(torch.rand(n, device=DEV, generator=g, dtype=torch.float64) * np.log(1e5))
