@@ -122,6 +122,39 @@ VMF_HD double bessel_ratio_eval(double v, double lg_v1, double lg_v, double x) {
   return ::exp(log_ive_pos(v, lg_v1, x) - log_ive_pos(v - 1.0, lg_v, x));
 }
 
+// ---- single-precision log ive for the fp32 log-normaliser (one evaluation per ROW of a 2^24-row batch) ---------
+// 7 Debye terms once v^2 + x^2 >= 100 (truncation < 2e-7 relative), the power series below that (x < 10: <= 35
+// terms, all positive).  Every quantity that cancels (r - x, log(x/(v+r))) is formed the same way as in double.
+#define VMF_DEBYE_R2_F32 100.0f
+#define VMF_DEBYE_K_F32 7
+VMF_HD float log_ive_pos_f32(float v, float lgam_v1, float x) {
+  if (v * v + x * x < VMF_DEBYE_R2_F32) {
+    const float q = 0.25f * x * x;
+    float term = 1.0f, sum = 1.0f;
+    for (int k = 1; k < 64; ++k) {
+      term *= q / ((float)k * (v + (float)k));
+      sum += term;
+      if (term < 1e-8f * sum) break;
+    }
+    return v * ::logf(0.5f * x) - lgam_v1 - x + ::logf(sum);
+  }
+  const float r = ::sqrtf(v * v + x * x);
+  const float p = v / r;
+  const float rmx = v * v / (r + x);
+  const float expo = rmx - v * ::log1pf((v + rmx) / x);
+  const float p2 = p * p, pv = 1.0f / r;
+  float pk = 1.0f, sum = 0.0f;
+#pragma unroll
+  for (int k = 0; k < VMF_DEBYE_K_F32; ++k) {
+    float poly = 0.0f;
+#pragma unroll
+    for (int j = k; j >= 0; --j) poly = poly * p2 + (float)DEBYE_U[k][j];
+    sum += pk * poly;
+    pk *= pv;
+  }
+  return expo - 0.5f * ::logf(6.28318530717958647692f * r) + ::logf(sum);
+}
+
 // vMF constants that depend on m only (host side)
 struct VmfDim {
   int m;
@@ -145,6 +178,10 @@ static inline VmfDim make_vmf_dim(int m) {
 // log C_m(k) = v log k - (m/2) log 2pi - (log ive(v,k) + k),  v = m/2 - 1
 VMF_HD double vmf_log_norm(const VmfDim& d, double k) {
   return d.v * ::log(k) - d.half_m_log2pi - (log_ive_pos(d.v, d.lg_v1, k) + k);
+}
+// the same in single precision (|error| ~ 1e-6 (1 + |log C_m|)); used when the output tensor is fp32
+VMF_HD float vmf_log_norm_f32(const VmfDim& d, float k) {
+  return (float)d.v * ::logf(k) - (float)d.half_m_log2pi - (log_ive_pos_f32((float)d.v, (float)d.lg_v1, k) + k);
 }
 // A_m(k) = I_{m/2}(k) / I_{m/2-1}(k)
 VMF_HD double vmf_mean_resultant(const VmfDim& d, double k) {

@@ -408,8 +408,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void vmf_log_norm_kernel(const T* __restrict__ kappa, int64_t kappa_stride,
                                                            T* __restrict__ out, int64_t n, VmfDim dim) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    out[i] = (T)vmf_log_norm(dim, (double)kappa[i * kappa_stride]);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (sizeof(T) == 4) out[i] = (T)vmf_log_norm_f32(dim, (float)kappa[i * kappa_stride]);
+    else out[i] = (T)vmf_log_norm(dim, (double)kappa[i * kappa_stride]);
+  }
 }
 
 // ---- launch plumbing ---------------------------------------------------------------------------------
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(256) void vmf_log_prob_rowterm_kernel(const T* __re
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const double k = (double)kappa[i * kappa_stride];
-    if (!BWD) out[i] = (T)vmf_log_norm(dim, k);
+    if (!BWD) out[i] = sizeof(T) == 4 ? (T)vmf_log_norm_f32(dim, (float)k) : (T)vmf_log_norm(dim, k);
     else out[i] = (T)(-(double)gl[i] * vmf_mean_resultant(dim, k));  // d log C_m / dk = -A_m(k)
   }
 }

@@ -27,6 +27,10 @@ void hc_log_norm(int m, const double* k, double* out, int64_t n) {
   VmfDim d = make_vmf_dim(m);
   for (int64_t i = 0; i < n; ++i) out[i] = vmf_log_norm(d, k[i]);
 }
+void hc_log_norm_f32(int m, const float* k, float* out, int64_t n) {
+  VmfDim d = make_vmf_dim(m);
+  for (int64_t i = 0; i < n; ++i) out[i] = vmf_log_norm_f32(d, k[i]);
+}
 void hc_kl_f64(const double* k, double* out, double* dout, int64_t n, int variant) {
   KlBessel kb = make_kl_bessel();
   for (int64_t i = 0; i < n; ++i) out[i] = kl_value<double>(k[i], variant, kb, &dout[i]);

@@ -73,6 +73,17 @@ def test_device_log_ive_ratio_lognorm_match_oracle(hc, oracle):
         np.testing.assert_allclose(out, ref, rtol=1e-11, atol=1e-9)
 
 
+def test_device_single_precision_log_normaliser(hc, oracle):
+    """the fp32 log C_m(kappa) used for fp32 log_prob outputs: within fp32 rounding of the double oracle"""
+    lib = oracle.lib()
+    for m in (2, 3, 10, 64, 512, 2048):
+        k = np.logspace(-2, 5, 141).astype(np.float32)
+        out = np.empty_like(k)
+        hc.hc_log_norm_f32(m, _p(k), _p(out), C.c_int64(k.size))
+        ref = np.array([lib.orc_vmf_log_norm_scalar(m, float(kk)) for kk in k])
+        np.testing.assert_allclose(out, ref, rtol=3e-6, atol=3e-6 * m)
+
+
 @pytest.mark.parametrize("tag", ["f64", "f32"])
 @pytest.mark.parametrize("name,variant", [("spherical", 0), ("torus", 1), ("circular", 2), ("s1", 3)])
 def test_device_kl_matches_reference(hc, golden, oracle, tag, name, variant):
