@@ -171,6 +171,47 @@ int vmf_s1_projnormal_bwd(const void* mean, const void* kappa, const void* noise
                           void* dkappa, int64_t n, int dim, uint64_t row0, uint64_t seed, uint64_t offset, int dtype,
                           vmf_stream_t stream);
 
+/* ---- the steps on either side of the sampler in the train step ------------------------------------------
+ * ELBO  model/spherical_vae.py:119-138 (= model/torus_vae.py:160-180, CNN_experiment/circular_VAE.py:90-116,
+ * and with sums instead of means regular_cnn/s1_vae.py:70-92):
+ *   loss = a_rec * sum_e (x[e mod n_x] - x_hat[e])^2 + a_kl * sum_i KL_variant(kappa_i)
+ * as one fused reduction.  x (n_x elements) repeats along the leading dimensions of x_hat (n_hat elements, a
+ * multiple of n_x) the way `x - x_mu` broadcasts when the sample is (B, B, 3).  The caller passes
+ * a_rec = gamma / n_hat and a_kl = beta / n_kappa for the reference's means.  loss_out: one element of `dtype`;
+ * parts_out (optional): two doubles {a_rec * sum, a_kl * sum}; workspace: VMF_ELBO_WORKSPACE_DOUBLES doubles.
+ * bwd: grad_loss is a DEVICE scalar of `dtype` (no host sync); d_x_hat / d_kappa may be NULL to skip. */
+#define VMF_ELBO_WORKSPACE_DOUBLES 2048
+int vmf_elbo_fwd(const void* x, const void* x_hat, const void* kappa, void* loss_out, double* parts_out,
+                 double* workspace, double a_rec, double a_kl, int64_t n_x, int64_t n_hat, int64_t n_kappa,
+                 int variant, int dtype, vmf_stream_t stream);
+int vmf_elbo_bwd(const void* x, const void* x_hat, const void* kappa, const void* grad_loss, void* d_x_hat,
+                 void* d_kappa, double a_rec, double a_kl, int64_t n_x, int64_t n_hat, int64_t n_kappa, int variant,
+                 int dtype, vmf_stream_t stream);
+
+/* Torus embedding  model/torus_vae.py:60-81: rows of z_theta / z_phi (n, zdim >= 2) hold (cos, sin) in their
+ * first two components; out (n, 3) = ((R + r cos t) cos p, (r + r cos t) sin p, r sin t)  (y as in :78).
+ * bwd writes full (n, zdim) gradients (components >= 2 are zero). */
+int vmf_build_torus_fwd(const void* z_theta, const void* z_phi, void* out, int64_t n, int zdim, double R, double r,
+                        int dtype, vmf_stream_t stream);
+int vmf_build_torus_bwd(const void* z_theta, const void* z_phi, const void* grad_out, void* g_theta, void* g_phi,
+                        int64_t n, int zdim, double R, double r, int dtype, vmf_stream_t stream);
+
+/* Supervised latent losses  dataloader/utils.py:101-180.  z (n, zdim) row-major, labels (n_labels, label_cols);
+ * row i of z pairs with label row i mod n_labels (z may carry leading broadcast dimensions).  mean_out: one
+ * element of `dtype` = mean over the n rows; per_row_out (optional): n elements; workspace:
+ * VMF_KL_WORKSPACE_DOUBLES doubles.  R, r are used by VMF_LL_T2 only.  bwd: grad_mean is a device scalar. */
+enum vmf_latent_loss_variant {
+  VMF_LATENT_S1 = 0, /* (1 - cos(atan2(z1, z0) - label0))^2                                   :113-123 */
+  VMF_LATENT_S2 = 1, /* (1 - cos(dtheta) + sin(theta_gt) sin(theta_hat) (1 - cos(dphi)))^2     :128-151 */
+  VMF_LATENT_T2 = 2  /* (1 - cos dtheta) + (1 - cos dphi) + 0.1 ((rho - R)^2 + z^2 - r^2)^2    :153-177 */
+};
+int vmf_latent_loss_fwd(const void* z, const void* labels, void* per_row_out, void* mean_out, double* workspace,
+                        int64_t n, int zdim, int64_t n_labels, int label_cols, int variant, double R, double r,
+                        int dtype, vmf_stream_t stream);
+int vmf_latent_loss_bwd(const void* z, const void* labels, const void* grad_mean, void* dz, int64_t n, int zdim,
+                        int64_t n_labels, int label_cols, int variant, double R, double r, int dtype,
+                        vmf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

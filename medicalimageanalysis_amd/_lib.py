@@ -15,6 +15,8 @@ _DEFAULT = os.path.join(_HERE, "libvmf_hip.so")
 VMF_F32, VMF_F64 = 0, 1
 KL_SPHERICAL_PIECEWISE, KL_TORUS_RAW, KL_CIRCULAR_EPS, KL_S1_I0I1, KL_STABLE_M3, KL_STABLE_M2 = range(6)
 KL_WORKSPACE_DOUBLES = 1024
+ELBO_WORKSPACE_DOUBLES = 2048
+LATENT_S1, LATENT_S2, LATENT_T2 = range(3)
 
 _P, _I64, _U64, _I, _D = C.c_void_p, C.c_int64, C.c_uint64, C.c_int, C.c_double
 _I64P = C.POINTER(C.c_int64)
@@ -42,6 +44,12 @@ _PROTOS = {
     "vmf_sphere_uniform_sample": [_P, _P, _I64, _I, _U64, _U64, _U64, _I, _P],
     "vmf_s1_projnormal_fwd": [_P, _P, _P, _P, _I64, _I, _U64, _U64, _U64, _I, _P],
     "vmf_s1_projnormal_bwd": [_P, _P, _P, _P, _P, _P, _I64, _I, _U64, _U64, _U64, _I, _P],
+    "vmf_elbo_fwd": [_P, _P, _P, _P, _P, _P, _D, _D, _I64, _I64, _I64, _I, _I, _P],
+    "vmf_elbo_bwd": [_P, _P, _P, _P, _P, _P, _D, _D, _I64, _I64, _I64, _I, _I, _P],
+    "vmf_build_torus_fwd": [_P, _P, _P, _I64, _I, _D, _D, _I, _P],
+    "vmf_build_torus_bwd": [_P, _P, _P, _P, _P, _I64, _I, _D, _D, _I, _P],
+    "vmf_latent_loss_fwd": [_P, _P, _P, _P, _P, _I64, _I, _I64, _I, _I, _D, _D, _I, _P],
+    "vmf_latent_loss_bwd": [_P, _P, _P, _P, _I64, _I, _I64, _I, _I, _D, _D, _I, _P],
 }
 EXPORTS = sorted(list(_PROTOS) + ["vmf_version", "vmf_last_error_string"])
 

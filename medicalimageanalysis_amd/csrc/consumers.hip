@@ -1,0 +1,371 @@
+// consumers.hip -- the steps on either side of the sampler in the reference's train step, each as one pass:
+//   * the ELBO (reconstruction MSE + KL mean) as one fused reduction        model/spherical_vae.py:119-138
+//   * the torus embedding of two sphere draws                               model/torus_vae.py:60-81
+//   * the supervised latent (geodesic) losses on S^1, S^2, T^2               dataloader/utils.py:101-180
+// All are HBM streams: x_hat (and z) are read once, sums are carried in double, the finish is one small block.
+#include "consumers_math.h"
+#include "vmf_math.h"
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+// 128-bit accesses of the fp32 fast path; streamed operands bypass the caches' retention (nontemporal)
+__device__ __forceinline__ void load4(const float* p, float* dst) {
+  v4f v = *reinterpret_cast<const v4f*>(p);
+  dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+}
+__device__ __forceinline__ void load4_stream(const float* p, float* dst) {
+  v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+  dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+}
+__device__ __forceinline__ void store4_stream(float* p, const float* src) {
+  v4f v = {src[0], src[1], src[2], src[3]};
+  __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
+}
+// never instantiated for double (the vector path is fp32 only); present so both branches type-check
+__device__ __forceinline__ void load4(const double*, double*) {}
+__device__ __forceinline__ void load4_stream(const double*, double*) {}
+__device__ __forceinline__ void store4_stream(double*, const double*) {}
+
+// ---- ELBO -------------------------------------------------------------------------------------------------
+// loss = a_rec * sum_e (x[e mod n_x] - x_hat[e])^2 + a_kl * sum_i KL(kappa_i)
+// x is broadcast over the leading dimensions of x_hat: with kappa of shape (B, 1) the reference's sample is
+// (B, B, 3), the decoder output (B, B, D), and `x - x_mu` repeats x (B, D) along the first axis.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void elbo_fwd_kernel(const T* __restrict__ x, const T* __restrict__ xhat,
+                                                       const T* __restrict__ kappa, double* __restrict__ partial,
+                                                       int64_t n_x, int64_t n_hat, int64_t n_kappa, int variant,
+                                                       KlBessel kb) {
+  __shared__ double red[4];
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  double acc_rec = 0, acc_kl = 0;
+  {
+    const int64_t step = nthreads * VEC;
+    const int64_t step_mod = step % n_x;
+    int64_t e = tid * VEC;
+    int64_t xi = e % n_x;
+    for (; e < n_hat; e += step) {
+      T a[VEC], b[VEC];
+      if (VEC == 4) {
+        load4(x + xi, a);
+        load4_stream(xhat + e, b);
+      } else {
+        a[0] = x[xi];
+        b[0] = xhat[e];
+      }
+      T s = 0;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        T d = a[j] - b[j];
+        s += d * d;
+      }
+      acc_rec += (double)s;
+      xi += step_mod;
+      if (xi >= n_x) xi -= n_x;
+    }
+  }
+  for (int64_t i = tid; i < n_kappa; i += nthreads) {
+    T g;
+    acc_kl += (double)kl_value<T>(kappa[i], variant, kb, &g);
+  }
+  double t0 = block_sum_double(acc_rec, red);
+  __syncthreads();
+  double t1 = block_sum_double(acc_kl, red);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = t0;
+    partial[gridDim.x + blockIdx.x] = t1;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void elbo_final_kernel(const double* __restrict__ partial, int nblk, double a_rec,
+                                                         double a_kl, T* __restrict__ loss,
+                                                         double* __restrict__ parts) {
+  __shared__ double red[4];
+  double r = 0, k = 0;
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+    r += partial[i];
+    k += partial[nblk + i];
+  }
+  double t0 = block_sum_double(r, red);
+  __syncthreads();
+  double t1 = block_sum_double(k, red);
+  if (threadIdx.x == 0) {
+    // the two terms are rounded to T before they are combined, as gamma * recon + beta * KL on T tensors is
+    *loss = (T)(a_rec * t0) + (T)(a_kl * t1);
+    if (parts) {
+      parts[0] = a_rec * t0;
+      parts[1] = a_kl * t1;
+    }
+  }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void elbo_bwd_kernel(const T* __restrict__ x, const T* __restrict__ xhat,
+                                                       const T* __restrict__ kappa, const T* __restrict__ gout,
+                                                       T a_rec, T a_kl, T* __restrict__ d_xhat,
+                                                       T* __restrict__ d_kappa, int64_t n_x, int64_t n_hat,
+                                                       int64_t n_kappa, int variant, KlBessel kb) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  const T go = gout[0];
+  if (d_xhat) {
+    const T c = (T)2 * a_rec * go;
+    const int64_t step = nthreads * VEC;
+    const int64_t step_mod = step % n_x;
+    int64_t e = tid * VEC;
+    int64_t xi = e % n_x;
+    for (; e < n_hat; e += step) {
+      T a[VEC], b[VEC], o[VEC];
+      if (VEC == 4) {
+        load4(x + xi, a);
+        load4_stream(xhat + e, b);
+      } else {
+        a[0] = x[xi];
+        b[0] = xhat[e];
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] = c * (b[j] - a[j]);
+      if (VEC == 4) store4_stream(d_xhat + e, o);
+      else d_xhat[e] = o[0];
+      xi += step_mod;
+      if (xi >= n_x) xi -= n_x;
+    }
+  }
+  if (d_kappa) {
+    const T c = a_kl * go;
+    for (int64_t i = tid; i < n_kappa; i += nthreads) {
+      T g;
+      kl_value<T>(kappa[i], variant, kb, &g);
+      d_kappa[i] = c * g;
+    }
+  }
+}
+
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" int vmf_elbo_fwd(const void* x, const void* x_hat, const void* kappa, void* loss_out, double* parts_out,
+                            double* workspace, double a_rec, double a_kl, int64_t n_x, int64_t n_hat,
+                            int64_t n_kappa, int variant, int dtype, vmf_stream_t stream) {
+  VMF_REQUIRE(n_x > 0 && n_hat >= 0 && n_kappa >= 0, VMF_ERR_BAD_ARG, "vmf_elbo_fwd: bad sizes");
+  VMF_REQUIRE(n_hat % n_x == 0, VMF_ERR_BAD_ARG, "vmf_elbo_fwd: n_hat %lld is not a multiple of n_x %lld",
+              (long long)n_hat, (long long)n_x);
+  VMF_REQUIRE(variant >= 0 && variant <= VMF_KL_STABLE_M2, VMF_ERR_BAD_ARG, "unknown KL variant %d", variant);
+  VMF_REQUIRE(dtype == VMF_F32 || dtype == VMF_F64, VMF_ERR_DTYPE, "dtype %d", dtype);
+  VMF_REQUIRE(x && loss_out && workspace && (n_hat == 0 || x_hat) && (n_kappa == 0 || kappa), VMF_ERR_BAD_ARG,
+              "vmf_elbo_fwd: null pointer");
+  KlBessel kb = make_kl_bessel();
+  const int es = dtype == VMF_F32 ? 4 : 8;
+  const bool vec = (n_x % 4 == 0) && aligned16(x) && aligned16(x_hat) && es == 4;
+  int64_t work = vec ? n_hat / 4 : n_hat;
+  if (work < n_kappa) work = n_kappa;
+  const int grid = vmf_grid_for(work, 256, VMF_ELBO_WORKSPACE_DOUBLES / 2);
+  if (vec) {
+    hipLaunchKernelGGL((elbo_fwd_kernel<float, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       (const float*)x_hat, (const float*)kappa, workspace, n_x, n_hat, n_kappa, variant, kb);
+  } else {
+    VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((elbo_fwd_kernel<T, 1>), dim3(grid), dim3(256), 0,
+                                                 (hipStream_t)stream, (const T*)x, (const T*)x_hat,
+                                                 (const T*)kappa, workspace, n_x, n_hat, n_kappa, variant, kb));
+  }
+  int rc = vmf_check_launch("vmf_elbo_fwd");
+  if (rc) return rc;
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(elbo_final_kernel<T>, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                                               workspace, grid, a_rec, a_kl, (T*)loss_out, parts_out));
+  return vmf_check_launch("vmf_elbo_fwd final");
+}
+
+extern "C" int vmf_elbo_bwd(const void* x, const void* x_hat, const void* kappa, const void* grad_loss,
+                            void* d_x_hat, void* d_kappa, double a_rec, double a_kl, int64_t n_x, int64_t n_hat,
+                            int64_t n_kappa, int variant, int dtype, vmf_stream_t stream) {
+  VMF_REQUIRE(n_x > 0 && n_hat >= 0 && n_kappa >= 0, VMF_ERR_BAD_ARG, "vmf_elbo_bwd: bad sizes");
+  VMF_REQUIRE(n_hat % n_x == 0, VMF_ERR_BAD_ARG, "vmf_elbo_bwd: n_hat is not a multiple of n_x");
+  VMF_REQUIRE(variant >= 0 && variant <= VMF_KL_STABLE_M2, VMF_ERR_BAD_ARG, "unknown KL variant %d", variant);
+  VMF_REQUIRE(dtype == VMF_F32 || dtype == VMF_F64, VMF_ERR_DTYPE, "dtype %d", dtype);
+  VMF_REQUIRE(grad_loss && (!d_x_hat || (x && x_hat)) && (!d_kappa || kappa), VMF_ERR_BAD_ARG,
+              "vmf_elbo_bwd: null pointer");
+  if ((!d_x_hat || n_hat == 0) && (!d_kappa || n_kappa == 0)) return VMF_OK;
+  KlBessel kb = make_kl_bessel();
+  const int es = dtype == VMF_F32 ? 4 : 8;
+  const bool vec = (n_x % 4 == 0) && aligned16(x) && aligned16(x_hat) && aligned16(d_x_hat) && es == 4;
+  int64_t work = d_x_hat ? (vec ? n_hat / 4 : n_hat) : 0;
+  if (d_kappa && work < n_kappa) work = n_kappa;
+  const int grid = vmf_grid_for(work, 256);
+  if (vec) {
+    hipLaunchKernelGGL((elbo_bwd_kernel<float, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       (const float*)x_hat, (const float*)kappa, (const float*)grad_loss, (float)a_rec, (float)a_kl,
+                       (float*)d_x_hat, (float*)d_kappa, n_x, n_hat, n_kappa, variant, kb);
+  } else {
+    VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((elbo_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0,
+                                                 (hipStream_t)stream, (const T*)x, (const T*)x_hat,
+                                                 (const T*)kappa, (const T*)grad_loss, (T)a_rec, (T)a_kl,
+                                                 (T*)d_x_hat, (T*)d_kappa, n_x, n_hat, n_kappa, variant, kb));
+  }
+  return vmf_check_launch("vmf_elbo_bwd");
+}
+
+// ---- torus embedding --------------------------------------------------------------------------------------
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void build_torus_kernel(const T* __restrict__ zt, const T* __restrict__ zp,
+                                                          const T* __restrict__ gout, T* __restrict__ out,
+                                                          T* __restrict__ gt, T* __restrict__ gp, int64_t n,
+                                                          int zdim, T R, T r) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const T ct = zt[i * zdim], st = zt[i * zdim + 1], cp = zp[i * zdim], sp = zp[i * zdim + 1];
+    if (!BWD) {
+      T o[3];
+      torus_point<T>(ct, st, cp, sp, R, r, o);
+      out[i * 3] = o[0];
+      out[i * 3 + 1] = o[1];
+      out[i * 3 + 2] = o[2];
+    } else {
+      T g[3] = {gout[i * 3], gout[i * 3 + 1], gout[i * 3 + 2]}, a[2], b[2];
+      torus_point_bwd<T>(ct, cp, sp, R, r, g, a, b);
+      gt[i * zdim] = a[0];
+      gt[i * zdim + 1] = a[1];
+      gp[i * zdim] = b[0];
+      gp[i * zdim + 1] = b[1];
+      for (int c = 2; c < zdim; ++c) {
+        gt[i * zdim + c] = (T)0;
+        gp[i * zdim + c] = (T)0;
+      }
+    }
+  }
+}
+
+extern "C" int vmf_build_torus_fwd(const void* z_theta, const void* z_phi, void* out, int64_t n, int zdim, double R,
+                                   double r, int dtype, vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0 && zdim >= 2, VMF_ERR_BAD_ARG, "vmf_build_torus_fwd: n %lld, zdim %d", (long long)n, zdim);
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(z_theta && z_phi && out, VMF_ERR_BAD_ARG, "vmf_build_torus_fwd: null pointer");
+  int grid = vmf_grid_for(n, 256);
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((build_torus_kernel<T, false>), dim3(grid), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)z_theta, (const T*)z_phi,
+                                               (const T*)nullptr, (T*)out, (T*)nullptr, (T*)nullptr, n, zdim, (T)R,
+                                               (T)r));
+  return vmf_check_launch("vmf_build_torus_fwd");
+}
+
+extern "C" int vmf_build_torus_bwd(const void* z_theta, const void* z_phi, const void* grad_out, void* g_theta,
+                                   void* g_phi, int64_t n, int zdim, double R, double r, int dtype,
+                                   vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0 && zdim >= 2, VMF_ERR_BAD_ARG, "vmf_build_torus_bwd: n %lld, zdim %d", (long long)n, zdim);
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(z_theta && z_phi && grad_out && g_theta && g_phi, VMF_ERR_BAD_ARG, "vmf_build_torus_bwd: null pointer");
+  int grid = vmf_grid_for(n, 256);
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((build_torus_kernel<T, true>), dim3(grid), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)z_theta, (const T*)z_phi,
+                                               (const T*)grad_out, (T*)nullptr, (T*)g_theta, (T*)g_phi, n, zdim,
+                                               (T)R, (T)r));
+  return vmf_check_launch("vmf_build_torus_bwd");
+}
+
+// ---- latent losses ------------------------------------------------------------------------------------------
+// Row i of z pairs with label row (i mod n_labels): z may carry leading broadcast dimensions ((B, B, 3) against
+// labels (B, L)), exactly as `latent_phi - gt_phi` broadcasts in dataloader/utils.py:121.
+#define VMF_LL_MAX_ZDIM 8
+
+template <typename T, bool GRAD>
+__device__ __forceinline__ T latent_loss_row(const T* zr, int zdim, const T* lab, int variant, T R, T r, T* dz) {
+  switch (variant) {
+    case VMF_LL_S1: return latent_loss_s1<T, GRAD>(zr, zdim, lab[0], dz);
+    case VMF_LL_S2: return latent_loss_s2<T, GRAD>(zr, zdim, lab[0], lab[1], dz);
+    default: return latent_loss_t2<T, GRAD>(zr, zdim, lab[0], lab[1], R, r, dz);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void latent_loss_fwd_kernel(const T* __restrict__ z, const T* __restrict__ labels,
+                                                              T* __restrict__ per_row, double* __restrict__ partial,
+                                                              int64_t n, int zdim, int64_t n_labels, int lcols,
+                                                              int variant, T R, T r) {
+  __shared__ double red[4];
+  double acc = 0;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    T zr[VMF_LL_MAX_ZDIM];
+    for (int c = 0; c < zdim; ++c) zr[c] = z[i * zdim + c];
+    const T* lab = labels + (i % n_labels) * lcols;
+    T v = latent_loss_row<T, false>(zr, zdim, lab, variant, R, r, nullptr);
+    if (per_row) per_row[i] = v;
+    acc += (double)v;
+  }
+  double t = block_sum_double(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void latent_loss_final_kernel(const double* __restrict__ partial, int nblk,
+                                                                double alpha, T* __restrict__ out) {
+  __shared__ double red[4];
+  double acc = 0;
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) acc += partial[i];
+  double t = block_sum_double(acc, red);
+  if (threadIdx.x == 0) *out = (T)(alpha * t);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void latent_loss_bwd_kernel(const T* __restrict__ z, const T* __restrict__ labels,
+                                                              const T* __restrict__ gout, T gscale,
+                                                              T* __restrict__ dz_out, int64_t n, int zdim,
+                                                              int64_t n_labels, int lcols, int variant, T R, T r) {
+  const T g = gout[0] * gscale;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    T zr[VMF_LL_MAX_ZDIM], dz[VMF_LL_MAX_ZDIM];
+    for (int c = 0; c < zdim; ++c) zr[c] = z[i * zdim + c];
+    const T* lab = labels + (i % n_labels) * lcols;
+    latent_loss_row<T, true>(zr, zdim, lab, variant, R, r, dz);
+    for (int c = 0; c < zdim; ++c) dz_out[i * zdim + c] = g * dz[c];
+  }
+}
+
+static int latent_loss_check(const char* who, int64_t n, int zdim, int64_t n_labels, int lcols, int variant) {
+  VMF_REQUIRE(variant >= VMF_LL_S1 && variant <= VMF_LL_T2, VMF_ERR_BAD_ARG, "%s: unknown variant %d", who, variant);
+  VMF_REQUIRE(n >= 0 && n_labels > 0, VMF_ERR_BAD_ARG, "%s: bad row counts", who);
+  VMF_REQUIRE(n % n_labels == 0, VMF_ERR_BAD_ARG, "%s: %lld rows of z do not tile %lld label rows", who,
+              (long long)n, (long long)n_labels);
+  const int need_z = variant == VMF_LL_S1 ? 2 : 3, need_l = variant == VMF_LL_S1 ? 1 : 2;
+  VMF_REQUIRE(zdim >= need_z && zdim <= VMF_LL_MAX_ZDIM, VMF_ERR_BAD_ARG, "%s: zdim %d outside [%d, %d]", who, zdim,
+              need_z, VMF_LL_MAX_ZDIM);
+  VMF_REQUIRE(lcols >= need_l, VMF_ERR_BAD_ARG, "%s: labels need %d columns, got %d", who, need_l, lcols);
+  return VMF_OK;
+}
+
+extern "C" int vmf_latent_loss_fwd(const void* z, const void* labels, void* per_row_out, void* mean_out,
+                                   double* workspace, int64_t n, int zdim, int64_t n_labels, int label_cols,
+                                   int variant, double R, double r, int dtype, vmf_stream_t stream) {
+  int rc = latent_loss_check("vmf_latent_loss_fwd", n, zdim, n_labels, label_cols, variant);
+  if (rc) return rc;
+  VMF_REQUIRE(dtype == VMF_F32 || dtype == VMF_F64, VMF_ERR_DTYPE, "dtype %d", dtype);
+  VMF_REQUIRE(mean_out && workspace && labels && (n == 0 || z), VMF_ERR_BAD_ARG, "vmf_latent_loss_fwd: null pointer");
+  int grid = vmf_grid_for(n, 256, VMF_KL_WORKSPACE_DOUBLES);
+  if (n > 0) {
+    VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(latent_loss_fwd_kernel<T>, dim3(grid), dim3(256), 0,
+                                                 (hipStream_t)stream, (const T*)z, (const T*)labels,
+                                                 (T*)per_row_out, workspace, n, zdim, n_labels, label_cols, variant,
+                                                 (T)R, (T)r));
+    rc = vmf_check_launch("vmf_latent_loss_fwd");
+    if (rc) return rc;
+  }
+  // mean over zero rows is NaN, as torch's .mean() of an empty tensor is
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(latent_loss_final_kernel<T>, dim3(1), dim3(256), 0,
+                                               (hipStream_t)stream, workspace, n > 0 ? grid : 0,
+                                               n > 0 ? 1.0 / (double)n : (double)NAN, (T*)mean_out));
+  return vmf_check_launch("vmf_latent_loss_fwd final");
+}
+
+extern "C" int vmf_latent_loss_bwd(const void* z, const void* labels, const void* grad_mean, void* dz, int64_t n,
+                                   int zdim, int64_t n_labels, int label_cols, int variant, double R, double r,
+                                   int dtype, vmf_stream_t stream) {
+  int rc = latent_loss_check("vmf_latent_loss_bwd", n, zdim, n_labels, label_cols, variant);
+  if (rc) return rc;
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(z && labels && grad_mean && dz, VMF_ERR_BAD_ARG, "vmf_latent_loss_bwd: null pointer");
+  int grid = vmf_grid_for(n, 256);
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(latent_loss_bwd_kernel<T>, dim3(grid), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)z, (const T*)labels,
+                                               (const T*)grad_mean, (T)(1.0 / (double)n), (T*)dz, n, zdim, n_labels,
+                                               label_cols, variant, (T)R, (T)r));
+  return vmf_check_launch("vmf_latent_loss_bwd");
+}

@@ -1,0 +1,128 @@
+// consumers_math.h -- per-row math of the steps on either side of the sampler: the torus embedding of two
+// sphere draws and the supervised latent (geodesic) losses.  __host__ __device__ so the host check library
+// can run the same functions on the CPU.
+#pragma once
+#include "common.h"
+
+template <typename T> struct MT;  // trigonometry the sampler itself never needs
+template <> struct MT<float> {
+  static VMF_HD float sin(float x) { return ::sinf(x); }
+  static VMF_HD float cos(float x) { return ::cosf(x); }
+  static VMF_HD float acos(float x) { return ::acosf(x); }
+  static VMF_HD float atan2(float y, float x) { return ::atan2f(y, x); }
+  static VMF_HD float fmod(float a, float b) { return ::fmodf(a, b); }
+};
+template <> struct MT<double> {
+  static VMF_HD double sin(double x) { return ::sin(x); }
+  static VMF_HD double cos(double x) { return ::cos(x); }
+  static VMF_HD double acos(double x) { return ::acos(x); }
+  static VMF_HD double atan2(double y, double x) { return ::atan2(y, x); }
+  static VMF_HD double fmod(double a, double b) { return ::fmod(a, b); }
+};
+
+// (phi + 2 pi) % (2 pi) as torch evaluates it: the Python scalar 2*pi is rounded to the tensor's dtype, and
+// torch's % is the floored modulo (result takes the divisor's sign); dataloader/utils.py:117,142,168-169
+template <typename T>
+VMF_HD T wrap_2pi(T a) {
+  const T two_pi = (T)6.283185307179586476925;
+  T r = MT<T>::fmod(a + two_pi, two_pi);
+  if (r < (T)0) r += two_pi;
+  return r;
+}
+
+// ---- torus embedding (model/torus_vae.py:60-81) --------------------------------------------------------------
+// (cos, sin) of each angle are the first two components of the two sphere draws; y uses (r + r cos theta),
+// as the reference does (:78).
+template <typename T>
+VMF_HD void torus_point(T ct, T st, T cp, T sp, T R, T r, T out[3]) {
+  out[0] = (R + r * ct) * cp;
+  out[1] = (r + r * ct) * sp;
+  out[2] = r * st;
+}
+// gradients wrt (ct, st) and (cp, sp) given g = d loss / d out
+template <typename T>
+VMF_HD void torus_point_bwd(T ct, T cp, T sp, T R, T r, const T g[3], T gt[2], T gp[2]) {
+  gt[0] = r * (cp * g[0] + sp * g[1]);
+  gt[1] = r * g[2];
+  gp[0] = (R + r * ct) * g[0];
+  gp[1] = (r + r * ct) * g[1];
+}
+
+// ---- latent losses (dataloader/utils.py:101-180), one row ----------------------------------------------------
+// Each returns the row's contribution l(z, label); the caller averages.  With GRAD the derivative wrt the row of z
+// is written to dz[0..zdim) (not yet scaled by the upstream gradient / row count).
+enum { VMF_LL_S1 = VMF_LATENT_S1, VMF_LL_S2 = VMF_LATENT_S2, VMF_LL_T2 = VMF_LATENT_T2 };
+
+template <typename T, bool GRAD>
+VMF_HD T latent_loss_s1(const T* z, int zdim, T gt_phi, T* dz) {
+  const T x = z[0], y = z[1];
+  T phi = wrap_2pi<T>(MT<T>::atan2(y, x));             // :116-117
+  T a = phi - gt_phi;
+  T d = MT<T>::cos(a);                                 // :121
+  T om = (T)1 - d;
+  if (GRAD) {
+    T dphi = (T)2 * om * MT<T>::sin(a);
+    T rho2 = x * x + y * y;
+    dz[0] = dphi * (-y / rho2);
+    dz[1] = dphi * (x / rho2);
+    for (int c = 2; c < zdim; ++c) dz[c] = (T)0;
+  }
+  return om * om;                                      // :122
+}
+
+template <typename T, bool GRAD>
+VMF_HD T latent_loss_s2(const T* z, int zdim, T theta_gt, T phi_gt, T* dz) {
+  T ss = (T)0;
+  for (int c = 0; c < zdim; ++c) ss += z[c] * z[c];
+  const T nrm = M<T>::sqrt(ss);                        // :134
+  const T x = z[0], y = z[1];
+  const T raw = z[2] / nrm;
+  const T zc = raw < (T)-1 ? (T)-1 : (raw > (T)1 ? (T)1 : raw);   // :138
+  const T theta_hat = MT<T>::acos(zc);                 // :140
+  const T phi_hat = wrap_2pi<T>(MT<T>::atan2(y, x));   // :141-142
+  const T dth = theta_gt - theta_hat, dph = phi_gt - phi_hat;
+  const T sgt = MT<T>::sin(theta_gt), sth = MT<T>::sin(theta_hat);
+  const T omc = (T)1 - MT<T>::cos(dph);
+  const T term1 = (T)1 - MT<T>::cos(dth);              // :147
+  const T term2 = sgt * sth * omc;                     // :148
+  const T s = term1 + term2;
+  if (GRAD) {
+    const T dl = (T)2 * s;
+    const T d_theta_hat = dl * (-MT<T>::sin(dth) + sgt * MT<T>::cos(theta_hat) * omc);
+    const T d_phi_hat = dl * (-(sgt * sth * MT<T>::sin(dph)));
+    // acos' = -1/sqrt(1-c^2); clamp passes the gradient only inside [-1, 1]
+    const T d_raw = (raw >= (T)-1 && raw <= (T)1) ? -d_theta_hat / M<T>::sqrt((T)1 - zc * zc) : (T)0;
+    const T rho2 = x * x + y * y;
+    const T n3 = nrm * nrm * nrm;
+    for (int c = 0; c < zdim; ++c) dz[c] = -d_raw * z[2] * z[c] / n3;
+    dz[2] += d_raw / nrm;
+    dz[0] += d_phi_hat * (-y / rho2);
+    dz[1] += d_phi_hat * (x / rho2);
+  }
+  return s * s;                                        // :149
+}
+
+template <typename T, bool GRAD>
+VMF_HD T latent_loss_t2(const T* z, int zdim, T l_theta, T l_phi, T R, T r, T* dz) {
+  const T x = z[0], y = z[1], zc = z[2];
+  const T rho = M<T>::sqrt(x * x + y * y);             // :162
+  const T s = rho - R;
+  const T phi = wrap_2pi<T>(MT<T>::atan2(y, x));       // :164,168
+  const T theta = wrap_2pi<T>(MT<T>::atan2(zc, s));    // :165,169
+  const T a = theta - l_theta, b = phi - l_phi;
+  const T q = s * s + zc * zc - r * r;                 // :174
+  // mean(1-cos a) + mean(1-cos b) + 0.1 mean(q^2)  ==  mean of the row value below (:172-177)
+  const T val = ((T)1 - MT<T>::cos(a)) + ((T)1 - MT<T>::cos(b)) + (T)0.1 * (q * q);
+  if (GRAD) {
+    const T d_theta = MT<T>::sin(a), d_phi = MT<T>::sin(b), d_q = (T)0.2 * q;
+    const T h2 = s * s + zc * zc;
+    const T d_s = d_theta * (-zc / h2) + d_q * (T)2 * s;
+    const T d_zc = d_theta * (s / h2) + d_q * (T)2 * zc;
+    const T rho2 = rho * rho;
+    dz[0] = d_s * (x / rho) + d_phi * (-y / rho2);
+    dz[1] = d_s * (y / rho) + d_phi * (x / rho2);
+    dz[2] = d_zc;
+    for (int c = 3; c < zdim; ++c) dz[c] = (T)0;
+  }
+  return val;
+}

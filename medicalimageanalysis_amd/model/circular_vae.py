@@ -4,6 +4,7 @@ import torch.nn as nn
 
 from ..sampler.von_mises_fisher import VonMisesFisher3DLogProb as VonMisesFisher3D
 from .. import kl as _kl
+from .. import losses as _losses
 
 
 class CircularVAE(nn.Module):
@@ -52,10 +53,7 @@ class CircularVAE(nn.Module):
     def _elbo(self, x, x_recon, posterior_params):
         z_mu, z_kappa = posterior_params
         q_z = VonMisesFisher3D(z_mu, z_kappa)
-        kappa = q_z.scale
-        KL = _kl.kl_mean(kappa, "circular")
-        reconstruction_loss = torch.mean((x - x_recon) * (x - x_recon))
-        return self.config["gamma"] * reconstruction_loss + self.config["beta"] * KL  # :106-116
+        return _losses.elbo_loss(x, x_recon, q_z.scale, self.config["gamma"], self.config["beta"], "circular")  # :106-116
 
     def kl_vmf_spherical_uniform(self, kappa) -> torch.Tensor:
         return _kl.kl_per_sample(kappa, "circular")  # :118-130

@@ -6,6 +6,7 @@ import torch.nn.functional as F
 
 from .. import _lib, rng
 from .. import kl as _kl
+from .. import losses as _losses
 
 
 class _S1ProjNormal(torch.autograd.Function):
@@ -86,7 +87,6 @@ class S1_VAE(nn.Module):
 def loss_function(recon_x, x, mean_vec, kappa):
     """sum-MSE + sum_i (k I1(k)/I0(k) - log I0(k))  (regular_cnn/s1_vae.py:70-92); overflows to NaN where the
     reference does (k > ~88.7 in fp32)."""
-    BCE = F.mse_loss(recon_x, x, reduction="sum")
-    k = kappa.squeeze()
-    KLD = _kl.kl_sum(k, "s1")
-    return BCE + KLD
+    if recon_x.shape != x.shape:  # F.mse_loss broadcasts (with a warning); keep that path on stock ops
+        return F.mse_loss(recon_x, x, reduction="sum") + _kl.kl_sum(kappa.squeeze(), "s1")
+    return _losses.elbo_loss(x, recon_x, kappa.squeeze(), 1.0, 1.0, "s1", reduction="sum")

@@ -11,6 +11,7 @@ from ..sampler.von_mises_fisher import *  # noqa: F401,F403
 from ..sampler.spherical_uniform import SphericalUniform
 from ..sampler.von_mises_fisher import VonMisesFisher3D
 from .. import kl as _kl
+from .. import losses as _losses
 
 
 class SphericalVAE(nn.Module):
@@ -70,15 +71,12 @@ class SphericalVAE(nn.Module):
 
     def _elbo(self, x, x_mu, posteriori_params):
         """gamma * mean((x - x_mu)^2) + beta * mean(KL)  (model/spherical_vae.py:119-138).  The distribution
-        objects are still constructed (argument checks, the m == 3 assertion) but the KL mean is one fused
-        reduction instead of mask gathers + two host syncs."""
+        objects are still constructed (argument checks, the m == 3 assertion); the squared error over the
+        broadcast (B, B, D) shape and the KL mean are ONE fused reduction (no mask gathers, no host syncs)."""
         z_mu, z_kappa = posteriori_params
         q_z = VonMisesFisher3D(z_mu, z_kappa)
         p_z = SphericalUniform(dim=self.latent_dim - 1, device=x.device)  # noqa: F841  (built, unused: :130)
-        kappa = q_z.scale
-        KL = _kl.kl_mean(kappa, "spherical")
-        reconstruction_loss = torch.mean((x - x_mu) * (x - x_mu))
-        return self.config["gamma"] * reconstruction_loss + self.config["beta"] * KL
+        return _losses.elbo_loss(x, x_mu, q_z.scale, self.config["gamma"], self.config["beta"], "spherical")
 
     def kl_vmf_spherical_uniform(self, kappa) -> torch.Tensor:
         """KL(vMF(mu, kappa) || Uniform(S^2)) per element, piecewise as model/spherical_vae.py:141-184."""

@@ -10,6 +10,7 @@ from ..sampler.von_mises_fisher import *  # noqa: F401,F403
 from ..sampler.spherical_uniform import SphericalUniform
 from ..sampler.von_mises_fisher import VonMisesFisher3D
 from .. import kl as _kl
+from .. import losses as _losses
 
 
 class ToroidalVAE(nn.Module):
@@ -45,13 +46,7 @@ class ToroidalVAE(nn.Module):
     def _build_torus(self, z_theta, z_phi):
         """model/torus_vae.py:60-81: the first two components of each sphere sample act as (cos, sin);
         y uses (r + r cos theta), as the reference does."""
-        cos_theta, sin_theta = z_theta[..., 0], z_theta[..., 1]
-        cos_phi, sin_phi = z_phi[..., 0], z_phi[..., 1]
-        R, r = self.longest_radius, self.shortes_radius
-        x = (R + r * cos_theta) * cos_phi
-        y = (r + r * cos_theta) * sin_phi
-        z = r * sin_theta
-        return torch.stack([x, y, z], dim=-1)
+        return _losses.build_torus(z_theta, z_phi, self.longest_radius, self.shortes_radius)
 
     def encode(self, x):
         h = F.softplus(self.encoder_function(x), beta=self.sftbeta)
@@ -89,10 +84,7 @@ class ToroidalVAE(nn.Module):
         z_mu, z_kappa = posteriori_params
         q_z = VonMisesFisher3D(z_mu, z_kappa)
         p_z = SphericalUniform(dim=self.latent_dim - 1, device=x.device)  # noqa: F841
-        kappa = q_z.scale
-        KL = _kl.kl_mean(kappa, "torus")
-        reconstruction_loss = torch.mean((x - x_mu) * (x - x_mu))
-        return self.config["gamma"] * reconstruction_loss + self.config["beta"] * KL
+        return _losses.elbo_loss(x, x_mu, q_z.scale, self.config["gamma"], self.config["beta"], "torus")
 
     def kl_vmf_spherical_uniform(self, kappa) -> torch.Tensor:
         """unguarded form of model/torus_vae.py:182-194 (NaN once sinh overflows, like the reference)"""

@@ -28,6 +28,10 @@ Files written (all float arrays keep the dtype the reference computed in):
   g_svae.npz      SphericalVAE fwd/_elbo/bwd model/spherical_vae.py:51-138
   g_cvae.npz      CircularVAE fwd/_elbo      CNN_experiment/circular_VAE.py:42-116
   g_s1.npz        S1_VAE reparam + loss      regular_cnn/s1_vae.py:44-92
+  g_consumers.npz _elbo on given tensors (executed: SphericalVAE._elbo model/spherical_vae.py:119-138,
+                  CircularVAE._elbo CNN_experiment/circular_VAE.py:90-116), with gradients; _build_torus
+                  (model/torus_vae.py:60-81) and latent_loss (dataloader/utils.py:101-180) by their formulas
+                  evaluated with torch ops + autograd (their modules import geomstats, not installed)
 """
 import importlib
 import os
@@ -358,10 +362,106 @@ def make_s1():
     np.savez_compressed(os.path.join(OUT, "g_s1.npz"), **out)
 
 
+def _latent_loss_formula(labels, z, dataset, R=None, r=None):
+    """dataloader/utils.py:101-180 evaluated with the same torch operations, in the same order"""
+    if dataset == "S1_dataset":
+        latent_phi = torch.atan2(z[..., 1], z[..., 0])
+        latent_phi = (latent_phi + (2 * torch.pi)) % (2 * torch.pi)
+        diff = torch.cos(latent_phi - labels[:, 0])
+        return ((1 - diff) ** 2).mean()
+    if dataset == "S2_dataset":
+        theta_gt, phi_gt = labels[:, 0], labels[:, 1]
+        z_norm = z / (z.norm(dim=-1, keepdim=True))
+        x, y = z[..., 0], z[..., 1]
+        z_comp = z_norm[..., 2].clamp(-1.0, 1.0)
+        theta_hat = torch.acos(z_comp)
+        phi_hat = torch.atan2(y, x)
+        phi_hat = (phi_hat + (2 * torch.pi)) % (2 * torch.pi)
+        dtheta, dphi = theta_gt - theta_hat, phi_gt - phi_hat
+        term1 = 1.0 - torch.cos(dtheta)
+        term2 = torch.sin(theta_gt) * torch.sin(theta_hat) * (1.0 - torch.cos(dphi))
+        return ((term1 + term2) ** 2).mean()
+    x, y, zc = z[..., 0], z[..., 1], z[..., 2]
+    rho = torch.sqrt(x ** 2 + y ** 2)
+    latent_phis = torch.atan2(y, x)
+    latent_thetas = torch.atan2(zc, rho - R)
+    latent_phis = (latent_phis + (2 * torch.pi)) % (2 * torch.pi)
+    latent_thetas = (latent_thetas + (2 * torch.pi)) % (2 * torch.pi)
+    thetas_loss = torch.mean(1 - torch.cos(latent_thetas - labels[:, 0]))
+    phis_loss = torch.mean(1 - torch.cos(latent_phis - labels[:, 1]))
+    torus_constraint = ((rho - R) ** 2 + zc ** 2 - r ** 2) ** 2
+    return (thetas_loss + phis_loss + 0.1 * torus_constraint).mean()
+
+
+def make_consumers():
+    out = {}
+    sv = _import_from(REF, "model.spherical_vae")
+    cfg = dict(extrinsic_dim=12, latent_dim=3, sftbeta=1.0, encoder_width=8, encoder_depth=1, decoder_width=8,
+               decoder_depth=1, dropout_p=0.0, device="cpu", gamma=0.7, beta=0.03)
+    torch.manual_seed(0)
+    smodel = sv.SphericalVAE(cfg)
+    cv = _import_from(os.path.join(REF, "CNN_experiment"), "circular_VAE")
+    ccfg = dict(device="cpu", extrinsic_dim=12, encoder_width=8, decoder_width=8, gamma=1.3, beta=0.2)
+    cmodel = cv.CircularVAE(ccfg)
+    gen = torch.Generator().manual_seed(77)
+    for tag, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        B, D = 9, 12
+        x = torch.randn(B, D, generator=gen, dtype=dt)
+        z_mu = torch.randn(B, 3, generator=gen, dtype=dt)
+        # spherical: x_mu (B, B, D), kappa (B, 1) spanning the three KL regions
+        x_mu = torch.randn(B, B, D, generator=gen, dtype=dt).requires_grad_()
+        kap = torch.tensor([1e-4, 0.5, 1.0, 5.0, 19.9, 20.1, 50.0, 100.0, 1e3], dtype=dt).reshape(B, 1).requires_grad_()
+        loss = smodel._elbo(x, x_mu, (z_mu, kap))
+        loss.backward()
+        out[f"sph_{tag}::x"], out[f"sph_{tag}::x_mu"], out[f"sph_{tag}::kappa"] = np_(x), np_(x_mu), np_(kap)
+        out[f"sph_{tag}::loss"], out[f"sph_{tag}::g_x_mu"], out[f"sph_{tag}::g_kappa"] = np_(loss), np_(x_mu.grad), np_(kap.grad)
+        # circular: x_recon (B, D), kappa (B,)
+        x_rec = torch.randn(B, D, generator=gen, dtype=dt).requires_grad_()
+        kap2 = (torch.rand(B, generator=gen, dtype=dt) * 40 + 1).requires_grad_()
+        loss = cmodel._elbo(x, x_rec, (z_mu, kap2))
+        loss.backward()
+        out[f"cir_{tag}::x"], out[f"cir_{tag}::x_mu"], out[f"cir_{tag}::kappa"] = np_(x), np_(x_rec), np_(kap2)
+        out[f"cir_{tag}::loss"], out[f"cir_{tag}::g_x_mu"], out[f"cir_{tag}::g_kappa"] = np_(loss), np_(x_rec.grad), np_(kap2.grad)
+        # torus embedding (model/torus_vae.py:60-81) on (B, B, 3) sphere draws and on raw (B, 3) means
+        R, r = 1.5, 0.5
+        for name, shape in (("bb", (B, B, 3)), ("b", (B, 3))):
+            zt = torch.nn.functional.normalize(torch.randn(*shape, generator=gen, dtype=dt), dim=-1).requires_grad_()
+            zp = torch.nn.functional.normalize(torch.randn(*shape, generator=gen, dtype=dt), dim=-1).requires_grad_()
+            ct, st, cp, sp = zt[..., 0], zt[..., 1], zp[..., 0], zp[..., 1]
+            tor = torch.stack([(R + r * ct) * cp, (r + r * ct) * sp, r * st], dim=-1)
+            c = torch.randn(*tor.shape, generator=gen, dtype=dt)
+            (tor * c).sum().backward()
+            k = f"tor_{name}_{tag}::"
+            out[k + "zt"], out[k + "zp"], out[k + "out"], out[k + "c"] = np_(zt), np_(zp), np_(tor), np_(c)
+            out[k + "g_zt"], out[k + "g_zp"] = np_(zt.grad), np_(zp.grad)
+        # latent losses: z (B, B, 3) (the broadcast sample) and (B, 3); T2 on points near the torus
+        for ds in ("S1_dataset", "S2_dataset", "T2_dataset"):
+            for name, shape in (("bb", (B, B, 3)), ("b", (B, 3))):
+                labels = torch.rand(B, 2, generator=gen, dtype=dt) * torch.tensor([np.pi, 2 * np.pi], dtype=dt)
+                if ds == "T2_dataset":
+                    labels = torch.rand(B, 2, generator=gen, dtype=dt) * (2 * np.pi)
+                    th = torch.rand(*shape[:-1], generator=gen, dtype=dt) * (2 * np.pi)
+                    ph = torch.rand(*shape[:-1], generator=gen, dtype=dt) * (2 * np.pi)
+                    z = torch.stack([(R + r * th.cos()) * ph.cos(), (R + r * th.cos()) * ph.sin(), r * th.sin()], -1)
+                    z = z + 0.05 * torch.randn(*shape, generator=gen, dtype=dt)
+                else:
+                    z = torch.nn.functional.normalize(torch.randn(*shape, generator=gen, dtype=dt), dim=-1)
+                    z = z * (1 + 0.01 * torch.randn(*shape[:-1], 1, generator=gen, dtype=dt))
+                z = z.clone().requires_grad_()
+                val = _latent_loss_formula(labels, z, ds, R, r)
+                val.backward()
+                k = f"ll_{ds[:2]}_{name}_{tag}::"
+                out[k + "labels"], out[k + "z"], out[k + "loss"], out[k + "g_z"] = np_(labels), np_(z), np_(val), np_(z.grad)
+    np.savez_compressed(os.path.join(OUT, "g_consumers.npz"), **out)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference not present: golden vectors can only be regenerated in the build container")
     torch.set_num_threads(1)
+    if sys.argv[1:] == ["consumers"]:
+        make_consumers()
+        sys.exit(0)
     make_rsample()
     make_grads()
     make_kl()
@@ -370,6 +470,7 @@ if __name__ == "__main__":
     make_svae()
     make_cvae()
     make_s1()
+    make_consumers()
     total = 0
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

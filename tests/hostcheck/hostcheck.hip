@@ -1,7 +1,8 @@
 // hostcheck.hip -- TEST ONLY.  Runs the library's __host__ __device__ per-element math (bessel_dev.h,
-// vmf_math.h) on the CPU so that the arithmetic the kernels execute can be compared with the oracle without a
+// vmf_math.h, consumers_math.h) on the CPU so that the arithmetic the kernels execute can be compared with the oracle without a
 // GPU.  It is not part of libvmf_hip.so and nothing in the package loads it.
 #include "../../medicalimageanalysis_amd/csrc/vmf_math.h"
+#include "../../medicalimageanalysis_amd/csrc/consumers_math.h"
 
 void vmf_set_error(const char*, ...) {}
 int vmf_check_launch(const char*) { return 0; }
@@ -31,6 +32,31 @@ void hc_log_norm_f32(int m, const float* k, float* out, int64_t n) {
   VmfDim d = make_vmf_dim(m);
   for (int64_t i = 0; i < n; ++i) out[i] = vmf_log_norm_f32(d, k[i]);
 }
+#define HC_LATENT(NAME, T)                                                                                       \
+  void NAME(const T* z, const T* labels, T* rows, T* dz, int64_t n, int zdim, int64_t nl, int lc, int variant,   \
+            T R, T r) {                                                                                          \
+    for (int64_t i = 0; i < n; ++i) {                                                                            \
+      const T* lab = labels + (i % nl) * lc;                                                                     \
+      T d[8];                                                                                                    \
+      T v;                                                                                                       \
+      if (variant == VMF_LL_S1) v = latent_loss_s1<T, true>(z + i * zdim, zdim, lab[0], d);                      \
+      else if (variant == VMF_LL_S2) v = latent_loss_s2<T, true>(z + i * zdim, zdim, lab[0], lab[1], d);         \
+      else v = latent_loss_t2<T, true>(z + i * zdim, zdim, lab[0], lab[1], R, r, d);                             \
+      rows[i] = v;                                                                                               \
+      for (int c = 0; c < zdim; ++c) dz[i * zdim + c] = d[c];                                                    \
+    }                                                                                                            \
+  }
+HC_LATENT(hc_latent_f64, double)
+HC_LATENT(hc_latent_f32, float)
+#define HC_TORUS(NAME, T)                                                                                        \
+  void NAME(const T* zt, const T* zp, const T* g, T* out, T* gt, T* gp, int64_t n, int zdim, T R, T r) {         \
+    for (int64_t i = 0; i < n; ++i) {                                                                            \
+      torus_point<T>(zt[i * zdim], zt[i * zdim + 1], zp[i * zdim], zp[i * zdim + 1], R, r, out + 3 * i);         \
+      torus_point_bwd<T>(zt[i * zdim], zp[i * zdim], zp[i * zdim + 1], R, r, g + 3 * i, gt + 2 * i, gp + 2 * i); \
+    }                                                                                                            \
+  }
+HC_TORUS(hc_torus_f64, double)
+HC_TORUS(hc_torus_f32, float)
 void hc_kl_f64(const double* k, double* out, double* dout, int64_t n, int variant) {
   KlBessel kb = make_kl_bessel();
   for (int64_t i = 0; i < n; ++i) out[i] = kl_value<double>(k[i], variant, kb, &dout[i]);

@@ -1,0 +1,284 @@
+"""HIP kernels for the steps on either side of the sampler (fused ELBO, torus embedding, latent losses) against the
+golden vectors, the numpy oracle and a torch-autograd restatement run on the same device.  Needs an MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs a HIP device", allow_module_level=True)
+
+from medicalimageanalysis_amd import _lib, losses  # noqa: E402
+from medicalimageanalysis_amd.model.torus_vae import ToroidalVAE  # noqa: E402
+from oracle import consumers_oracle as co  # noqa: E402
+
+DEV = torch.device("cuda:0")
+TD = {"f64": torch.float64, "f32": torch.float32}
+TOL = {"f64": dict(rtol=1e-10, atol=1e-12), "f32": dict(rtol=1e-4, atol=1e-6)}
+DATASETS = {"S1": "S1_dataset", "S2": "S2_dataset", "T2": "T2_dataset"}
+
+
+def T(a, dtype=None):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+# ---- ELBO -------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("model,variant,gamma,beta", [("sph", "spherical", 0.7, 0.03), ("cir", "circular", 1.3, 0.2)])
+def test_elbo_matches_reference_values_and_gradients(golden, tag, model, variant, gamma, beta):
+    g = golden("g_consumers")
+    k = f"{model}_{tag}::"
+    x = T(g[k + "x"])
+    x_mu = T(g[k + "x_mu"]).requires_grad_()
+    kap = T(g[k + "kappa"]).requires_grad_()
+    loss = losses.elbo_loss(x, x_mu, kap, gamma, beta, variant)
+    assert loss.shape == () and loss.dtype == TD[tag]
+    np.testing.assert_allclose(N(loss), g[k + "loss"], **TOL[tag])
+    loss.backward()
+    np.testing.assert_allclose(N(x_mu.grad), g[k + "g_x_mu"], **TOL[tag])
+    gk = g[k + "g_kappa"]
+    np.testing.assert_allclose(N(kap.grad), gk, rtol=TOL[tag]["rtol"], atol=TOL[tag]["atol"] + 1e-6 * np.abs(gk).max())
+
+
+def test_elbo_through_the_c_abi_with_parts():
+    """direct call: loss, its two parts, workspace contract"""
+    torch.manual_seed(0)
+    B, D = 64, 784
+    x = torch.rand(B, D, device=DEV)
+    xh = torch.rand(B, B, D, device=DEV)
+    kap = torch.rand(B, 1, device=DEV) * 50 + 1
+    loss = torch.empty((), device=DEV)
+    parts = torch.empty(2, device=DEV, dtype=torch.float64)
+    ws = torch.empty(_lib.ELBO_WORKSPACE_DOUBLES, device=DEV, dtype=torch.float64)
+    rc = _lib.lib().vmf_elbo_fwd(_lib.ptr(x), _lib.ptr(xh), _lib.ptr(kap), _lib.ptr(loss), _lib.ptr(parts),
+                                 _lib.ptr(ws), 1.0 / xh.numel(), 0.01 / B, x.numel(), xh.numel(), B,
+                                 _lib.KL_SPHERICAL_PIECEWISE, _lib.VMF_F32, _lib.stream_ptr(DEV))
+    assert rc == 0
+    ref = co.elbo(N(x), N(xh), N(kap), 1.0, 0.01, "spherical")
+    np.testing.assert_allclose(N(loss), ref, rtol=2e-6)
+    rec64 = float(((x.double() - xh.double()) ** 2).mean())
+    np.testing.assert_allclose(N(parts)[0], rec64, rtol=1e-6)      # fp32 squares, double accumulation
+    assert abs(N(parts).sum() - float(loss)) < 1e-6
+    # n_hat not a multiple of n_x is an argument error, not a launch
+    rc = _lib.lib().vmf_elbo_fwd(_lib.ptr(x), _lib.ptr(xh), _lib.ptr(kap), _lib.ptr(loss), None, _lib.ptr(ws), 1.0,
+                                 1.0, x.numel(), xh.numel() - 1, B, 0, _lib.VMF_F32, _lib.stream_ptr(DEV))
+    assert rc == -1 and b"multiple" in _lib.lib().vmf_last_error_string()
+
+
+@pytest.mark.parametrize("shape_x,shape_h", [((5, 7), (5, 7)), ((5, 7), (3, 5, 7)), ((1, 7), (5, 7)), ((5, 1), (5, 6)),
+                                             ((6,), (2, 3, 6)), ((4, 8), (4, 4, 8)), ((2, 3), (5, 2, 3))])
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_elbo_broadcast_shapes_vs_torch_autograd(shape_x, shape_h, tag):
+    """scalar path, 128-bit path, materialised broadcasts, gradient of x"""
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    dt = TD[tag]
+    x = torch.randn(*shape_x, device=DEV, dtype=dt, generator=gen).requires_grad_()
+    xh = torch.randn(*shape_h, device=DEV, dtype=dt, generator=gen).requires_grad_()
+    kap = (torch.rand(9, device=DEV, dtype=dt, generator=gen) * 30 + 0.5).requires_grad_()
+    up = torch.tensor(1.7, device=DEV, dtype=dt)
+    (losses.elbo_loss(x, xh, kap, 0.9, 0.4, "torus") * up).backward()
+    got = [N(t.grad) for t in (x, xh, kap)]
+    for t in (x, xh, kap):
+        t.grad = None
+    sh = torch.sinh(kap)
+    kl = torch.log(kap) - torch.log(sh) + kap * (torch.cosh(kap) / sh) - 1.0
+    ref = 0.9 * torch.mean((x - xh) * (x - xh)) + 0.4 * kl.mean()
+    np.testing.assert_allclose(N(losses.elbo_loss(x, xh, kap, 0.9, 0.4, "torus")), N(ref), **TOL[tag])
+    (ref * up).backward()
+    for a, t in zip(got, (x, xh, kap)):
+        np.testing.assert_allclose(a, N(t.grad), rtol=TOL[tag]["rtol"], atol=10 * TOL[tag]["atol"])
+
+
+def test_elbo_sum_reduction_is_the_s1_loss():
+    """regular_cnn/s1_vae.py:70-92: mse_sum + sum_i (k I1/I0 - log I0)"""
+    from medicalimageanalysis_amd.model.s1_vae import loss_function
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.rand(16, 3, 8, 8, device=DEV, generator=gen)
+    rx = torch.rand(16, 3, 8, 8, device=DEV, generator=gen).requires_grad_()
+    kap = (torch.rand(16, 1, device=DEV, generator=gen) * 20 + 1).requires_grad_()
+    val = loss_function(rx, x, None, kap)
+    k = kap.squeeze()
+    ref = torch.nn.functional.mse_loss(rx, x, reduction="sum") + torch.sum(
+        k * (torch.special.i1(k) / torch.special.i0(k)) - torch.log(torch.special.i0(k)))
+    np.testing.assert_allclose(N(val), N(ref), rtol=2e-6)
+    val.backward()
+    g1, g2 = N(rx.grad), N(kap.grad)
+    rx.grad = kap.grad = None
+    ref.backward()
+    np.testing.assert_allclose(g1, N(rx.grad), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(g2, N(kap.grad), rtol=2e-4, atol=1e-5)
+
+
+def test_elbo_full_size_properties():
+    """B = 128, 28x28: x_hat (128, 128, 784) = 51 MB.  loss(x, x) has a zero reconstruction term; scaling the
+    residual by 2 scales it by 4; nan in x_hat propagates"""
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    B, D = 128, 784
+    x = torch.rand(B, D, device=DEV, generator=gen)
+    kap = torch.rand(B, 1, device=DEV, generator=gen) * 99 + 1
+    xh = x.expand(B, B, D).contiguous()
+    kl_only = losses.elbo_loss(x, xh, kap, 1.0, 1.0, "spherical")
+    np.testing.assert_allclose(N(kl_only), co.elbo(N(x), N(x), N(kap), 0.0, 1.0), rtol=1e-6)
+    r = torch.randn(B, B, D, device=DEV, generator=gen)
+    a = losses.elbo_loss(x, xh + r, kap, 1.0, 0.0, "spherical")
+    b = losses.elbo_loss(x, xh + 2 * r, kap, 1.0, 0.0, "spherical")
+    np.testing.assert_allclose(N(b), 4 * N(a), rtol=1e-5)
+    np.testing.assert_allclose(N(a), float((r.double() ** 2).mean()), rtol=1e-5)
+    xh[5, 7, 11] = float("nan")
+    assert torch.isnan(losses.elbo_loss(x, xh, kap, 1.0, 1.0, "spherical"))
+
+
+# ---- torus embedding -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("name", ["bb", "b"])
+def test_build_torus_matches_goldens(golden, tag, name):
+    g = golden("g_consumers")
+    k = f"tor_{name}_{tag}::"
+    zt, zp = T(g[k + "zt"]).requires_grad_(), T(g[k + "zp"]).requires_grad_()
+    out = losses.build_torus(zt, zp, 1.5, 0.5)
+    assert out.shape == g[k + "out"].shape
+    np.testing.assert_allclose(N(out), g[k + "out"], **TOL[tag])
+    (out * T(g[k + "c"])).sum().backward()
+    np.testing.assert_allclose(N(zt.grad), g[k + "g_zt"], **TOL[tag])
+    np.testing.assert_allclose(N(zp.grad), g[k + "g_zp"], **TOL[tag])
+
+
+def test_build_torus_model_method_and_broadcast():
+    cfg = dict(extrinsic_dim=6, latent_dim=3, sftbeta=1.0, encoder_width=8, encoder_depth=1, decoder_width=8,
+               decoder_depth=1, dropout_p=0.0, device="cuda", gamma=1.0, beta=0.1, longest_radius=1.5,
+               shortest_radius=0.5)
+    model = ToroidalVAE(cfg)
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    zt = torch.randn(4, 1, 3, device=DEV, generator=gen).requires_grad_()
+    zp = torch.randn(1, 5, 3, device=DEV, generator=gen).requires_grad_()
+    out = model._build_torus(zt, zp)
+    assert out.shape == (4, 5, 3)
+    ref = torch.stack([(1.5 + 0.5 * zt[..., 0]) * zp[..., 0], (0.5 + 0.5 * zt[..., 0]) * zp[..., 1],
+                       0.5 * zt[..., 1].expand(4, 5)], dim=-1)
+    np.testing.assert_allclose(N(out), N(ref), rtol=1e-6, atol=1e-7)
+    c = torch.randn(4, 5, 3, device=DEV, generator=gen)
+    (out * c).sum().backward()
+    g1, g2 = N(zt.grad), N(zp.grad)
+    zt.grad = zp.grad = None
+    (ref * c).sum().backward()
+    np.testing.assert_allclose(g1, N(zt.grad), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(g2, N(zp.grad), rtol=1e-5, atol=1e-6)
+    with pytest.raises(IndexError):
+        losses.build_torus(torch.randn(3, 1, device=DEV), torch.randn(3, 1, device=DEV), 1.5, 0.5)
+
+
+# ---- latent losses -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("ds", list(DATASETS))
+@pytest.mark.parametrize("name", ["bb", "b"])
+def test_latent_loss_matches_goldens(golden, tag, ds, name):
+    g = golden("g_consumers")
+    k = f"ll_{ds}_{name}_{tag}::"
+    cfg = {"dataset": DATASETS[ds], "longest_radius": 1.5, "shortest_radius": 0.5}
+    z = T(g[k + "z"]).requires_grad_()
+    val = losses.latent_loss(T(g[k + "labels"]), z, cfg)
+    assert val.shape == ()
+    np.testing.assert_allclose(N(val), g[k + "loss"], **TOL[tag])
+    val.backward()
+    gz = g[k + "g_z"]
+    np.testing.assert_allclose(N(z.grad), gz, rtol=20 * TOL[tag]["rtol"],
+                               atol=(1e-12 if tag == "f64" else 2e-5 * np.abs(gz).max()))
+
+
+@pytest.mark.parametrize("ds", list(DATASETS))
+def test_latent_loss_large_batch_vs_oracle_and_per_row(ds):
+    """2^20 rows against the numpy oracle; per-row output of the C entry point; row -> label pairing by modulo"""
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    B, rep = 1 << 14, 64
+    z = torch.randn(rep, B, 3, device=DEV, dtype=torch.float64, generator=gen)
+    if ds == "T2":
+        z = z * 0.3 + torch.tensor([1.2, 0.9, 0.0], device=DEV, dtype=torch.float64)
+    labels = torch.rand(B, 2, device=DEV, dtype=torch.float64, generator=gen) * 3.0
+    cfg = {"dataset": DATASETS[ds], "longest_radius": 1.5, "shortest_radius": 0.5}
+    val = losses.latent_loss(labels, z, cfg)
+    rows_ref = co.latent_loss_rows(N(labels), N(z), DATASETS[ds], 1.5, 0.5)
+    np.testing.assert_allclose(N(val), rows_ref.mean(), rtol=1e-12)
+    n = rep * B
+    rows = torch.empty(n, device=DEV, dtype=torch.float64)
+    mean = torch.empty((), device=DEV, dtype=torch.float64)
+    ws = torch.empty(_lib.KL_WORKSPACE_DOUBLES, device=DEV, dtype=torch.float64)
+    rc = _lib.lib().vmf_latent_loss_fwd(_lib.ptr(z), _lib.ptr(labels), _lib.ptr(rows), _lib.ptr(mean), _lib.ptr(ws), n, 3,
+                                        B, 2, list(DATASETS).index(ds), 1.5, 0.5, _lib.VMF_F64, _lib.stream_ptr(DEV))
+    assert rc == 0
+    np.testing.assert_allclose(N(rows).reshape(rep, B), rows_ref, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(N(mean), N(val), rtol=1e-14)
+
+
+def test_latent_loss_errors_and_empty():
+    z = torch.randn(4, 3, device=DEV)
+    lab = torch.rand(4, 2, device=DEV)
+    with pytest.raises(ValueError, match="Unknown dataset"):
+        losses.latent_loss(lab, z, {"dataset": "points_dataset"})
+    with pytest.raises(RuntimeError):
+        losses.latent_loss(torch.rand(3, 2, device=DEV), z, {"dataset": "S2_dataset"})
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        losses.latent_loss(lab.cpu(), z.cpu(), {"dataset": "S1_dataset"})
+    # labels with one column are enough for S1 only
+    losses.latent_loss(lab[:, :1].contiguous(), z, {"dataset": "S1_dataset"})
+    with pytest.raises(RuntimeError, match="columns"):
+        losses.latent_loss(lab[:, :1].contiguous(), z, {"dataset": "S2_dataset"})
+    # unknown variant through the C ABI
+    ws = torch.empty(_lib.KL_WORKSPACE_DOUBLES, device=DEV, dtype=torch.float64)
+    out = torch.empty((), device=DEV)
+    rc = _lib.lib().vmf_latent_loss_fwd(_lib.ptr(z), _lib.ptr(lab), None, _lib.ptr(out), _lib.ptr(ws), 4, 3, 4, 2, 7,
+                                        0.0, 0.0, _lib.VMF_F32, _lib.stream_ptr(DEV))
+    assert rc == -1
+
+
+def test_train_step_t2_with_fused_consumers_matches_torch_ops():
+    """ToroidalVAE step as model/train.py:67-80 runs it (two _elbo calls + latent loss on the embedded means):
+    loss and parameter gradients against the same step written with torch ops on the device"""
+    cfg = dict(extrinsic_dim=10, latent_dim=3, sftbeta=1.0, encoder_width=16, encoder_depth=2, decoder_width=16,
+               decoder_depth=2, dropout_p=0.0, device="cuda", gamma=1.0, beta=0.05, alpha=0.3, longest_radius=1.5,
+               shortest_radius=0.5, dataset="T2_dataset")
+    torch.manual_seed(0)
+    model = ToroidalVAE(cfg).double()
+    B = 12
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.rand(B, 10, device=DEV, dtype=torch.float64, generator=gen)
+    labels = torch.rand(B, 2, device=DEV, dtype=torch.float64, generator=gen) * 6.28
+
+    def step(fused):
+        torch.manual_seed(4)
+        for p in model.parameters():
+            p.grad = None
+        z, x_mu, (tm, tk, pm, pk) = model(x)
+        if fused:
+            zl = model._build_torus(tm, pm)
+            loss = model._elbo(x, x_mu, (tm, tk)) + model._elbo(x, x_mu, (pm, pk))
+            loss = loss + cfg["alpha"] * losses.latent_loss(labels, zl, cfg)
+        else:
+            R, r = 1.5, 0.5
+            zl = torch.stack([(R + r * tm[..., 0]) * pm[..., 0], (r + r * tm[..., 0]) * pm[..., 1], r * tm[..., 1]], -1)
+            rec = torch.mean((x - x_mu) * (x - x_mu))
+
+            def kl(k):
+                return (torch.log(k) - torch.log(torch.sinh(k)) + k * torch.cosh(k) / torch.sinh(k) - 1.0).mean()
+            loss = 2 * cfg["gamma"] * rec + cfg["beta"] * (kl(tk) + kl(pk))
+            xx, yy, zc = zl[..., 0], zl[..., 1], zl[..., 2]
+            rho = torch.sqrt(xx ** 2 + yy ** 2)
+            ph = (torch.atan2(yy, xx) + 2 * torch.pi) % (2 * torch.pi)
+            th = (torch.atan2(zc, rho - R) + 2 * torch.pi) % (2 * torch.pi)
+            ll = torch.mean(1 - torch.cos(th - labels[:, 0])) + torch.mean(1 - torch.cos(ph - labels[:, 1])) + \
+                0.1 * ((rho - R) ** 2 + zc ** 2 - r ** 2) ** 2
+            loss = loss + cfg["alpha"] * ll.mean()
+        loss.backward()
+        return float(loss.detach()), [p.grad.clone() for p in model.parameters()]
+
+    la, ga = step(True)
+    lb, gb = step(False)
+    assert abs(la - lb) < 1e-11 * max(1, abs(lb))
+    for a, b in zip(ga, gb):
+        np.testing.assert_allclose(N(a), N(b), rtol=1e-8, atol=1e-11)
