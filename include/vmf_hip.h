@@ -17,7 +17,10 @@
  *   - tensors are dense row-major.
  *   - counter-based noise: Philox4x32-10 with key {seed_lo, seed_hi ^ offset_hi} and counter
  *     {index_lo, index_hi, slot, offset_lo}; `index` is the GLOBAL row / element index, so a batch sharded
- *     by rows over several GPUs draws the same numbers as the unsharded batch.
+ *     by rows over several GPUs draws the same numbers as the unsharded batch.  Every sampling entry point
+ *     takes the host `offset` and an optional device pointer `offset_dev` (one uint64, may be NULL): the kernel
+ *     uses offset + *offset_dev.  A launch captured into a HIP graph has its host arguments frozen; with the
+ *     counter in device memory (advanced by the caller between launches) every replay draws fresh noise.
  */
 #ifndef VMF_HIP_H
 #define VMF_HIP_H
@@ -28,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VMF_HIP_VERSION 100
+#define VMF_HIP_VERSION 110
 
 typedef void* vmf_stream_t; /* hipStream_t */
 
@@ -72,7 +75,7 @@ const char* vmf_last_error_string(void);
 int vmf3_rsample_fwd(const void* loc, const void* scale, const void* u, const void* eps, void* z, void* w_out,
                      int ndim, const int64_t* odims, const int64_t* w_str, const int64_t* k_str,
                      const int64_t* l_str, const int64_t* e_str, int dtype, uint64_t seed, uint64_t offset,
-                     vmf_stream_t stream);
+                     const uint64_t* offset_dev, vmf_stream_t stream);
 
 /* Backward of the above (what autograd derives from sampler/von_mises_fisher.py:30, 58-84):
  * dloc (n_loc rows of 3) and dscale (n_scale) receive J^T grad_z.  They are overwritten.  When several
@@ -80,7 +83,7 @@ int vmf3_rsample_fwd(const void* loc, const void* scale, const void* u, const vo
 int vmf3_rsample_bwd(const void* loc, const void* scale, const void* u, const void* eps, const void* grad_z,
                      void* dloc, void* dscale, int64_t n_loc, int64_t n_scale, int ndim, const int64_t* odims,
                      const int64_t* w_str, const int64_t* k_str, const int64_t* l_str, const int64_t* e_str,
-                     int dtype, uint64_t seed, uint64_t offset, vmf_stream_t stream);
+                     int dtype, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream);
 
 /* CNN_experiment/von_mises_fisher.py:88-108 with the reference's sign: logp = k<l,x> - lognorm,
  * lognorm = log k - log 4pi - log(sinh k + 1e-10).  logp / lognorm nullable. */
@@ -138,14 +141,14 @@ int vmf_kl_bwd(const void* kappa, const void* gout, int64_t gout_stride, double 
 int vmf_rsample_fwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, void* z, void* w_out,
                     void* omw_out, int32_t* accept_idx, void* logp_out, int64_t n, int m, const void* prop_e, const void* prop_u,
                     int n_prop, const void* gauss, int max_prop, uint64_t row0, uint64_t seed, uint64_t offset,
-                    int dtype, vmf_stream_t stream);
+                    const uint64_t* offset_dev, int dtype, vmf_stream_t stream);
 /* Backward through z given the saved w and 1-w (omw; null: 1-w is recomputed from w) -- path-wise through
  * b(kappa), the accepted proposal held fixed.
  * gauss null: the Gaussians are regenerated from the same counters.  dmu is (n, m); with mu_stride == 0 or
  * kappa_stride == 0 the caller reduces dmu / dkappa over rows. */
 int vmf_rsample_bwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, const void* w,
                     const void* omw, const void* grad_z, const void* gauss, void* dmu, void* dkappa, int64_t n, int m, uint64_t row0,
-                    uint64_t seed, uint64_t offset, int dtype, vmf_stream_t stream);
+                    uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int dtype, vmf_stream_t stream);
 /* logp = k<mu,x> + log C_m(k),  log C_m = (m/2-1) log k - (m/2) log 2pi - (log ive(m/2-1,k) + k) */
 int vmf_log_prob_fwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, const void* x,
                      void* logp, int64_t n, int m, int dtype, vmf_stream_t stream);
@@ -162,14 +165,15 @@ int vmf_entropy_kl_fwd(const void* kappa, void* entropy, void* kl, void* dkl_dk,
  * SphericalUniform.sample (sampler/spherical_uniform.py:31-33): out = g/||g||, g (n, dim) normals; g null:
  * Philox(index row0+i, slot 0x20000 + chunk). */
 int vmf_sphere_uniform_sample(const void* gauss, void* out, int64_t n, int dim, uint64_t row0, uint64_t seed,
-                              uint64_t offset, int dtype, vmf_stream_t stream);
+                              uint64_t offset, const uint64_t* offset_dev, int dtype, vmf_stream_t stream);
 /* S1_VAE.reparameterize (regular_cnn/s1_vae.py:48-55): z = normalize(mean*kappa + noise) with F.normalize's
  * eps 1e-12; mean/noise/z (n, dim), kappa (n); noise null: Philox as above with slot 0x30000 + chunk. */
 int vmf_s1_projnormal_fwd(const void* mean, const void* kappa, const void* noise, void* z, int64_t n, int dim,
-                          uint64_t row0, uint64_t seed, uint64_t offset, int dtype, vmf_stream_t stream);
-int vmf_s1_projnormal_bwd(const void* mean, const void* kappa, const void* noise, const void* gz, void* dmean,
-                          void* dkappa, int64_t n, int dim, uint64_t row0, uint64_t seed, uint64_t offset, int dtype,
+                          uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int dtype,
                           vmf_stream_t stream);
+int vmf_s1_projnormal_bwd(const void* mean, const void* kappa, const void* noise, const void* gz, void* dmean,
+                          void* dkappa, int64_t n, int dim, uint64_t row0, uint64_t seed, uint64_t offset,
+                          const uint64_t* offset_dev, int dtype, vmf_stream_t stream);
 
 /* ---- the steps on either side of the sampler in the train step ------------------------------------------
  * ELBO  model/spherical_vae.py:119-138 (= model/torus_vae.py:160-180, CNN_experiment/circular_VAE.py:90-116,

@@ -23,9 +23,9 @@ _I64P = C.POINTER(C.c_int64)
 
 # name -> argtypes; every function returns int except the two noted below
 _PROTOS = {
-    "vmf3_rsample_fwd": [_P, _P, _P, _P, _P, _P, _I, _I64P, _I64P, _I64P, _I64P, _I64P, _I, _U64, _U64, _P],
+    "vmf3_rsample_fwd": [_P, _P, _P, _P, _P, _P, _I, _I64P, _I64P, _I64P, _I64P, _I64P, _I, _U64, _U64, _P, _P],
     "vmf3_rsample_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I64P, _I64P, _I64P, _I64P, _I64P, _I, _U64,
-                         _U64, _P],
+                         _U64, _P, _P],
     "vmf3_log_prob_ref": [_P, _P, _P, _P, _P, _I64, _I, _P],
     "vmf3_log_prob_ref_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _P],
     "vmf3_mean": [_P, _P, _P, _I64, _I, _P],
@@ -35,15 +35,15 @@ _PROTOS = {
     "vmf_bessel_ratio_fwd": [_D, _P, _P, _I64, _I, _P],
     "vmf_kl_fwd": [_P, _P, _P, _P, _D, _I64, _I, _I, _P],
     "vmf_kl_bwd": [_P, _P, _I64, _D, _P, _I64, _I, _I, _P],
-    "vmf_rsample_fwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _I, _P, _I, _U64, _U64, _U64, _I,
-                        _P],
-    "vmf_rsample_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I, _U64, _U64, _U64, _I, _P],
+    "vmf_rsample_fwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _I, _P, _I, _U64, _U64, _U64, _P,
+                        _I, _P],
+    "vmf_rsample_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I, _U64, _U64, _U64, _P, _I, _P],
     "vmf_log_prob_fwd": [_P, _I64, _P, _I64, _P, _P, _I64, _I, _I, _P],
     "vmf_log_prob_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _I, _I, _P],
     "vmf_entropy_kl_fwd": [_P, _P, _P, _P, _I64, _I, _I, _P],
-    "vmf_sphere_uniform_sample": [_P, _P, _I64, _I, _U64, _U64, _U64, _I, _P],
-    "vmf_s1_projnormal_fwd": [_P, _P, _P, _P, _I64, _I, _U64, _U64, _U64, _I, _P],
-    "vmf_s1_projnormal_bwd": [_P, _P, _P, _P, _P, _P, _I64, _I, _U64, _U64, _U64, _I, _P],
+    "vmf_sphere_uniform_sample": [_P, _P, _I64, _I, _U64, _U64, _U64, _P, _I, _P],
+    "vmf_s1_projnormal_fwd": [_P, _P, _P, _P, _I64, _I, _U64, _U64, _U64, _P, _I, _P],
+    "vmf_s1_projnormal_bwd": [_P, _P, _P, _P, _P, _P, _I64, _I, _U64, _U64, _U64, _P, _I, _P],
     "vmf_elbo_fwd": [_P, _P, _P, _P, _P, _P, _D, _D, _I64, _I64, _I64, _I, _I, _P],
     "vmf_elbo_bwd": [_P, _P, _P, _P, _P, _P, _D, _D, _I64, _I64, _I64, _I, _I, _P],
     "vmf_build_torus_fwd": [_P, _P, _P, _I64, _I, _D, _D, _I, _P],

@@ -48,12 +48,32 @@ static inline int vmf_grid_for(int64_t work_items, int block, int max_blocks = 2
 struct PhiloxKey {
   uint32_t k0, k1, c3;  // key words and the 4th counter word (offset_lo)
 };
-static inline PhiloxKey make_philox_key(uint64_t seed, uint64_t offset) {
+// What a launch carries: seed, host offset and an optional DEVICE-resident 64-bit offset that is added to the host
+// one when the kernel starts.  With the counter in device memory a captured HIP graph draws fresh noise on every
+// replay (the host arguments of a captured launch are frozen).
+struct PhiloxArg {
+  uint32_t seed_lo, seed_hi, off_lo, off_hi;
+  const uint64_t* dev_offset;
+};
+static inline PhiloxArg make_philox_arg(uint64_t seed, uint64_t offset, const uint64_t* dev_offset) {
+  PhiloxArg a;
+  a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+  a.off_lo = (uint32_t)offset; a.off_hi = (uint32_t)(offset >> 32);
+  a.dev_offset = dev_offset;
+  return a;
+}
+VMF_HD PhiloxKey philox_key_from(uint64_t seed, uint64_t offset) {
   PhiloxKey k;
   k.k0 = (uint32_t)seed;
   k.k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32);
   k.c3 = (uint32_t)offset;
   return k;
+}
+// uniform across the grid: one scalar load
+__device__ __forceinline__ PhiloxKey philox_resolve(const PhiloxArg& a) {
+  uint64_t off = ((uint64_t)a.off_hi << 32) | a.off_lo;
+  if (a.dev_offset) off += *a.dev_offset;
+  return philox_key_from(((uint64_t)a.seed_hi << 32) | a.seed_lo, off);
 }
 
 struct U4 {

@@ -198,7 +198,8 @@ __device__ __forceinline__ T row_normal(const T* g, int64_t i, int dim, int c, u
 
 template <typename T>
 __global__ __launch_bounds__(256) void sphere_uniform_kernel(const T* __restrict__ gauss, T* __restrict__ out,
-                                                             int64_t n, int dim, uint64_t row0, PhiloxKey key) {
+                                                             int64_t n, int dim, uint64_t row0, PhiloxArg ka) {
+  const PhiloxKey key = philox_resolve(ka);
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     T cache[4];
@@ -216,11 +217,12 @@ __global__ __launch_bounds__(256) void sphere_uniform_kernel(const T* __restrict
 }
 
 extern "C" int vmf_sphere_uniform_sample(const void* gauss, void* out, int64_t n, int dim, uint64_t row0,
-                                         uint64_t seed, uint64_t offset, int dtype, vmf_stream_t stream) {
+                                         uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int dtype,
+                                         vmf_stream_t stream) {
   VMF_REQUIRE(n >= 0 && dim >= 1, VMF_ERR_BAD_ARG, "bad n/dim");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(out, VMF_ERR_BAD_ARG, "vmf_sphere_uniform_sample: null out");
-  PhiloxKey key = make_philox_key(seed, offset);
+  PhiloxArg key = make_philox_arg(seed, offset, offset_dev);
   int grid = vmf_grid_for(n, 256);
   VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(sphere_uniform_kernel<T>, dim3(grid), dim3(256), 0,
                                                (hipStream_t)stream, (const T*)gauss, (T*)out, n, dim, row0, key));
@@ -233,7 +235,8 @@ __global__ __launch_bounds__(256) void s1_projnormal_kernel(const T* __restrict_
                                                             const T* __restrict__ noise, const T* __restrict__ gz,
                                                             T* __restrict__ z, T* __restrict__ dmean,
                                                             T* __restrict__ dkappa, int64_t n, int dim,
-                                                            uint64_t row0, PhiloxKey key) {
+                                                            uint64_t row0, PhiloxArg ka) {
+  const PhiloxKey key = philox_resolve(ka);
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     T cache[4];
@@ -264,12 +267,12 @@ __global__ __launch_bounds__(256) void s1_projnormal_kernel(const T* __restrict_
 }
 
 extern "C" int vmf_s1_projnormal_fwd(const void* mean, const void* kappa, const void* noise, void* z, int64_t n,
-                                     int dim, uint64_t row0, uint64_t seed, uint64_t offset, int dtype,
-                                     vmf_stream_t stream) {
+                                     int dim, uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                     int dtype, vmf_stream_t stream) {
   VMF_REQUIRE(n >= 0 && dim >= 1, VMF_ERR_BAD_ARG, "bad n/dim");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(mean && kappa && z, VMF_ERR_BAD_ARG, "vmf_s1_projnormal_fwd: null pointer");
-  PhiloxKey key = make_philox_key(seed, offset);
+  PhiloxArg key = make_philox_arg(seed, offset, offset_dev);
   int grid = vmf_grid_for(n, 256);
   VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((s1_projnormal_kernel<T, false>), dim3(grid), dim3(256), 0,
                                                (hipStream_t)stream, (const T*)mean, (const T*)kappa,
@@ -280,11 +283,11 @@ extern "C" int vmf_s1_projnormal_fwd(const void* mean, const void* kappa, const 
 
 extern "C" int vmf_s1_projnormal_bwd(const void* mean, const void* kappa, const void* noise, const void* gz,
                                      void* dmean, void* dkappa, int64_t n, int dim, uint64_t row0, uint64_t seed,
-                                     uint64_t offset, int dtype, vmf_stream_t stream) {
+                                     uint64_t offset, const uint64_t* offset_dev, int dtype, vmf_stream_t stream) {
   VMF_REQUIRE(n >= 0 && dim >= 1, VMF_ERR_BAD_ARG, "bad n/dim");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(mean && kappa && gz && dmean && dkappa, VMF_ERR_BAD_ARG, "vmf_s1_projnormal_bwd: null pointer");
-  PhiloxKey key = make_philox_key(seed, offset);
+  PhiloxArg key = make_philox_arg(seed, offset, offset_dev);
   int grid = vmf_grid_for(n, 256);
   VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((s1_projnormal_kernel<T, true>), dim3(grid), dim3(256), 0,
                                                (hipStream_t)stream, (const T*)mean, (const T*)kappa,

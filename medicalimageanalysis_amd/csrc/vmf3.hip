@@ -106,7 +106,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void vmf3_fwd_kernel(const T* __restrict__ loc, const T* __restrict__ scale,
                                                        const T* __restrict__ u, const T* __restrict__ eps,
                                                        T* __restrict__ z, T* __restrict__ w_out, Bcast bc,
-                                                       int64_t n_out, PhiloxKey key) {
+                                                       int64_t n_out, PhiloxArg ka) {
+  const PhiloxKey key = philox_resolve(ka);
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += stride) {
     int64_t wi, ki, li, ei;
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(256) void vmf3_bwd_kernel(const T* __restrict__ loc
                                                        const T* __restrict__ u, const T* __restrict__ eps,
                                                        const T* __restrict__ gz, T* __restrict__ dloc,
                                                        T* __restrict__ dscale, Bcast bc, int64_t n_out,
-                                                       PhiloxKey key) {
+                                                       PhiloxArg ka) {
+  const PhiloxKey key = philox_resolve(ka);
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += stride) {
     int64_t wi, ki, li, ei;
@@ -162,14 +164,15 @@ __global__ __launch_bounds__(256) void vmf3_bwd_kernel(const T* __restrict__ loc
 extern "C" int vmf3_rsample_fwd(const void* loc, const void* scale, const void* u, const void* eps, void* z,
                                 void* w_out, int ndim, const int64_t* odims, const int64_t* w_str,
                                 const int64_t* k_str, const int64_t* l_str, const int64_t* e_str, int dtype,
-                                uint64_t seed, uint64_t offset, vmf_stream_t stream) {
+                                uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                vmf_stream_t stream) {
   Bcast bc;
   int64_t n_out = 0;
   int rc = make_bcast(&bc, &n_out, ndim, odims, w_str, k_str, l_str, e_str);
   if (rc) return rc;
   if (n_out == 0) return VMF_OK;
   VMF_REQUIRE(loc && scale && z, VMF_ERR_BAD_ARG, "vmf3_rsample_fwd: null loc/scale/z");
-  PhiloxKey key = make_philox_key(seed, offset);
+  PhiloxArg key = make_philox_arg(seed, offset, offset_dev);
   int grid = vmf_grid_for(n_out, 256);
   VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(vmf3_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                                (const T*)loc, (const T*)scale, (const T*)u, (const T*)eps, (T*)z,
@@ -181,7 +184,7 @@ extern "C" int vmf3_rsample_bwd(const void* loc, const void* scale, const void* 
                                 const void* grad_z, void* dloc, void* dscale, int64_t n_loc, int64_t n_scale,
                                 int ndim, const int64_t* odims, const int64_t* w_str, const int64_t* k_str,
                                 const int64_t* l_str, const int64_t* e_str, int dtype, uint64_t seed,
-                                uint64_t offset, vmf_stream_t stream) {
+                                uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream) {
   Bcast bc;
   int64_t n_out = 0;
   int rc = make_bcast(&bc, &n_out, ndim, odims, w_str, k_str, l_str, e_str);
@@ -199,7 +202,7 @@ extern "C" int vmf3_rsample_bwd(const void* loc, const void* scale, const void* 
       return vmf_check_launch("vmf3_rsample_bwd memset");
   }
   if (n_out == 0) return VMF_OK;
-  PhiloxKey key = make_philox_key(seed, offset);
+  PhiloxArg key = make_philox_arg(seed, offset, offset_dev);
   int grid = vmf_grid_for(n_out, 256);
   VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(vmf3_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                                (const T*)loc, (const T*)scale, (const T*)u, (const T*)eps,

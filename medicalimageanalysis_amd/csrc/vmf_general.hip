@@ -37,7 +37,7 @@ struct GenParams {
   T* z; T* w_out; T* omw_out; int32_t* accept_idx; T* logp;
   const T* prop_e; const T* prop_u; const T* gauss;
   int64_t n; int m; int max_prop; uint64_t row0;
-  PhiloxKey key; VmfDim dim;
+  PhiloxArg ka; VmfDim dim;
   // backward only
   const T* w_in; const T* omw_in; const T* gz; T* dmu; T* dkappa;
 };
@@ -100,7 +100,7 @@ struct FwdParams {
   const T* prop_e; const T* prop_u; const T* gauss;
   int64_t n; uint64_t row0;
   int mu_stride, kappa_stride, m, max_prop;
-  PhiloxKey key;
+  PhiloxArg ka;
 };
 
 // Prefetch of the next step's mu rows for the fp32 streaming kernel.  The load is issued from inline asm so that its
@@ -131,6 +131,7 @@ template <typename T, int LPR, int P, int MODE>
 __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2) ? 8 : 1) void vmf_rsample_fwd_kernel(FwdParams<T> p) {
   constexpr bool VEC = MODE >= 1;
   constexpr bool FAST = MODE == 2;
+  const PhiloxKey key = philox_resolve(p.ka);  // scalar: seed + host offset (+ device-resident offset)
   __shared__ T s_w[WAVES][TILE_ROWS];
   __shared__ T s_omw[WAVES][TILE_ROWS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
             const int64_t row = tile0 + my;
             acc = wood_try<T>(a, b, d, m, p.prop_e[row * p.max_prop + k], p.prop_u[row * p.max_prop + k], &w, &omw);
           } else {
-            const U4 r = philox4x32_10(grow0 + (uint64_t)my, (uint32_t)k, p.key);
+            const U4 r = philox4x32_10(grow0 + (uint64_t)my, (uint32_t)k, key);
             acc = wood_try_counter<T>(b, m, u01<T>(r.x), u01<T>(r.y), u01<T>(r.z), &w, &omw);
           }
           if (k + 1 >= p.max_prop) acc = true;  // the last proposal allowed is taken regardless
@@ -247,11 +248,11 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
       for (int j = 0; j < P; ++j) {
         const int chunk = j * LPR + sub;
         if (FAST) {
-          philox_normal4<T>(grow0 + (uint64_t)rr, SLOT_GAUSS + (uint32_t)chunk, p.key, g[j]);
+          philox_normal4<T>(grow0 + (uint64_t)rr, SLOT_GAUSS + (uint32_t)chunk, key, g[j]);
           if (j == 0 && sub == 0) g[0][0] = (T)0;
         } else {
           load4<T, VEC>(mrow, 4 * chunk, m, mu[j]);
-          noise4<T, VEC>(ga_t ? ga_t + (int64_t)rr * m : nullptr, grow0 + (uint64_t)rr, chunk, m, p.key, g[j]);
+          noise4<T, VEC>(ga_t ? ga_t + (int64_t)rr * m : nullptr, grow0 + (uint64_t)rr, chunk, m, key, g[j]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
 // Backward: one pass over (grad_z, mu) rows; normals regenerated from the counters unless given.
 template <typename T, int LPR, int P, bool VEC>
 __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T> p) {
+  const PhiloxKey key = philox_resolve(p.ka);
   const int lane = threadIdx.x & 63;
   constexpr int RPI = 64 / LPR;
   const int sub = lane % LPR, grp = lane / LPR;
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
       const int chunk = j * LPR + sub;
       load4<T, VEC>(mrow, 4 * chunk, m, mu[j]);
       load4<T, VEC>(grow_, 4 * chunk, m, G[j]);
-      noise4<T, VEC>(p.gauss ? p.gauss + row * (int64_t)m : nullptr, p.row0 + (uint64_t)row, chunk, m, p.key, g[j]);
+      noise4<T, VEC>(p.gauss ? p.gauss + row * (int64_t)m : nullptr, p.row0 + (uint64_t)row, chunk, m, key, g[j]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bool first = (chunk == 0 && i == 0);
@@ -453,14 +455,14 @@ template <typename T>
 static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, void* z,
                          void* w_out, void* omw_out, int32_t* accept_idx, void* logp_out, int64_t n, int m,
                          const void* prop_e, const void* prop_u, int n_prop, const void* gauss, int max_prop,
-                         uint64_t row0, uint64_t seed, uint64_t offset, hipStream_t s) {
+                         uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t s) {
   FwdParams<T> p = {};
   p.mu = (const T*)mu; p.kappa = (const T*)kappa; p.z = (T*)z;
   p.w_out = (T*)w_out; p.omw_out = (T*)omw_out; p.accept_idx = accept_idx; p.logp = (T*)logp_out;
   p.prop_e = (const T*)prop_e; p.prop_u = (const T*)prop_u; p.gauss = (const T*)gauss;
   p.n = n; p.row0 = row0; p.mu_stride = (int)mu_stride; p.kappa_stride = (int)kappa_stride; p.m = m;
   p.max_prop = prop_e ? n_prop : max_prop;
-  p.key = make_philox_key(seed, offset);
+  p.ka = make_philox_arg(seed, offset, offset_dev);
   const bool vec = (m % 4 == 0) && (mu_stride % 4 == 0) && aligned16(mu) && aligned16(z) && (!gauss || aligned16(gauss));
   const int chunks = (m + 3) / 4;
   int lpr = 1;
@@ -486,7 +488,8 @@ static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
 extern "C" int vmf_rsample_fwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, void* z,
                                void* w_out, void* omw_out, int32_t* accept_idx, void* logp_out, int64_t n, int m,
                                const void* prop_e, const void* prop_u, int n_prop, const void* gauss, int max_prop,
-                               uint64_t row0, uint64_t seed, uint64_t offset, int dtype, vmf_stream_t stream) {
+                               uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int dtype,
+                               vmf_stream_t stream) {
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
   VMF_REQUIRE(m >= 2, VMF_ERR_BAD_ARG, "m=%d < 2", m);
   VMF_REQUIRE(m <= 2048, VMF_ERR_UNSUPPORTED, "m=%d > 2048 is not supported", m);
@@ -504,7 +507,7 @@ extern "C" int vmf_rsample_fwd(const void* mu, int64_t mu_stride, const void* ka
   int rc;
   VMF_DISPATCH_DTYPE(dtype, rc = rsample_fwd_t<T>(mu, mu_stride, kappa, kappa_stride, z, w_out, omw_out, accept_idx,
                                                   logp_out, n, m, prop_e, prop_u, n_prop, gauss, max_prop, row0,
-                                                  seed, offset, (hipStream_t)stream));
+                                                  seed, offset, offset_dev, (hipStream_t)stream));
   if (rc) return rc;
   return vmf_check_launch("vmf_rsample_fwd");
 }
@@ -512,10 +515,10 @@ extern "C" int vmf_rsample_fwd(const void* mu, int64_t mu_stride, const void* ka
 template <typename T>
 static int rsample_bwd_t(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, const void* w,
                          const void* omw, const void* gz, const void* gauss, void* dmu, void* dkappa, int64_t n,
-                         int m, uint64_t row0, uint64_t seed, uint64_t offset, hipStream_t s) {
+                         int m, uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t s) {
   GenParams<T> p = {};
   p.mu = (const T*)mu; p.mu_stride = mu_stride; p.kappa = (const T*)kappa; p.kappa_stride = kappa_stride;
-  p.gauss = (const T*)gauss; p.n = n; p.m = m; p.row0 = row0; p.key = make_philox_key(seed, offset);
+  p.gauss = (const T*)gauss; p.n = n; p.m = m; p.row0 = row0; p.ka = make_philox_arg(seed, offset, offset_dev);
   p.dim = make_vmf_dim(m);
   p.w_in = (const T*)w; p.omw_in = (const T*)omw; p.gz = (const T*)gz; p.dmu = (T*)dmu; p.dkappa = (T*)dkappa;
   const bool vec = (m % 4 == 0) && (mu_stride % 4 == 0) && aligned16(mu) && aligned16(gz) && aligned16(dmu) &&
@@ -536,7 +539,7 @@ static int rsample_bwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
 extern "C" int vmf_rsample_bwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride,
                                const void* w, const void* omw, const void* grad_z, const void* gauss, void* dmu,
                                void* dkappa, int64_t n, int m, uint64_t row0, uint64_t seed, uint64_t offset,
-                               int dtype, vmf_stream_t stream) {
+                               const uint64_t* offset_dev, int dtype, vmf_stream_t stream) {
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
   VMF_REQUIRE(m >= 2, VMF_ERR_BAD_ARG, "m=%d < 2", m);
   VMF_REQUIRE(m <= 2048, VMF_ERR_UNSUPPORTED, "m=%d > 2048 is not supported", m);
@@ -546,7 +549,7 @@ extern "C" int vmf_rsample_bwd(const void* mu, int64_t mu_stride, const void* ka
   VMF_REQUIRE(mu && kappa && w && grad_z && dmu && dkappa, VMF_ERR_BAD_ARG, "vmf_rsample_bwd: null pointer");
   int rc;
   VMF_DISPATCH_DTYPE(dtype, rc = rsample_bwd_t<T>(mu, mu_stride, kappa, kappa_stride, w, omw, grad_z, gauss, dmu,
-                                                  dkappa, n, m, row0, seed, offset, (hipStream_t)stream));
+                                                  dkappa, n, m, row0, seed, offset, offset_dev, (hipStream_t)stream));
   if (rc) return rc;
   return vmf_check_launch("vmf_rsample_bwd");
 }

@@ -1,0 +1,56 @@
+"""Whole-step HIP graph capture for the launch-bound train step.
+
+At the reference's batch sizes (B = 128, latent S^2) a VAE step is ~100 tiny launches; the GPU is idle between them.
+Every entry point of libvmf_hip.so is asynchronous, allocation-free and never synchronises, so forward + loss +
+backward + optimizer step can be captured once and replayed as one graph launch.  Noise stays fresh across replays:
+torch's generator is capture-aware (VMF_RNG=torch), and the in-kernel Philox streams read their call counter from
+device memory (rng.PhiloxGenerator.enable_device_counter).
+"""
+import torch
+
+from . import rng
+
+
+class GraphedTrainStep:
+    """step = GraphedTrainStep(model, optimizer, loss_fn, example_inputs); loss = step(*inputs)
+
+    loss_fn(model, *inputs) -> scalar loss.  The optimizer must keep its state on the device
+    (e.g. torch.optim.Adam(..., capturable=True)).  Inputs are copied into static buffers, so their shapes and
+    dtypes are fixed at construction.  The returned loss is a static tensor that the next call overwrites."""
+
+    def __init__(self, model, optimizer, loss_fn, example_inputs, warmup=3, generator=None):
+        for group in optimizer.param_groups:
+            if "capturable" in group and not group["capturable"]:
+                raise ValueError("GraphedTrainStep needs an optimizer with capturable=True (its step counter must "
+                                 "live on the device)")
+        self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
+        self.static_inputs = [t.clone() for t in example_inputs]
+        dev = self.static_inputs[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("GraphedTrainStep runs on a HIP device only")
+        if rng.rng_mode() == "philox":
+            (generator or rng.default_generator).enable_device_counter(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # warm-up off the capture stream: lazy initialisations, optimizer state
+            for _ in range(warmup):
+                self._eager_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.static_loss = self._eager_step(zero=False)
+
+    def _eager_step(self, zero=True):
+        if zero:
+            self.optimizer.zero_grad(set_to_none=True)
+        loss = self.loss_fn(self.model, *self.static_inputs)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def __call__(self, *inputs):
+        for dst, src in zip(self.static_inputs, inputs):
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.static_loss

@@ -11,7 +11,7 @@ from .. import losses as _losses
 
 class _S1ProjNormal(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mean_vec, kappa, noise, seed, offset):
+    def forward(ctx, mean_vec, kappa, noise, seed, offset, offset_dev=None):
         dev = _lib.require_hip(mean_vec, kappa, noise)
         n, dim = mean_vec.shape
         mc = mean_vec.detach().contiguous()
@@ -20,10 +20,12 @@ class _S1ProjNormal(torch.autograd.Function):
         z = torch.empty_like(mc)
         with torch.cuda.device(dev):
             rc = _lib.lib().vmf_s1_projnormal_fwd(_lib.ptr(mc), _lib.ptr(kc), _lib.ptr(nc), _lib.ptr(z), n, dim, 0,
-                                                  seed, offset, _lib.dtype_code(mc), _lib.stream_ptr(dev))
+                                                  seed, offset, _lib.ptr(offset_dev), _lib.dtype_code(mc),
+                                                  _lib.stream_ptr(dev))
         _lib.check(rc, "vmf_s1_projnormal_fwd")
         ctx.save_for_backward(mc, kc, nc)
         ctx.meta = (seed, offset, kappa.shape)
+        ctx.offset_dev = offset_dev
         return z
 
     @staticmethod
@@ -36,18 +38,19 @@ class _S1ProjNormal(torch.autograd.Function):
         dm, dk = torch.empty_like(mc), torch.empty_like(kc)
         with torch.cuda.device(dev):
             rc = _lib.lib().vmf_s1_projnormal_bwd(_lib.ptr(mc), _lib.ptr(kc), _lib.ptr(nc), _lib.ptr(g), _lib.ptr(dm),
-                                                  _lib.ptr(dk), n, dim, 0, seed, offset, _lib.dtype_code(mc),
+                                                  _lib.ptr(dk), n, dim, 0, seed, offset, _lib.ptr(ctx.offset_dev),
+                                                  _lib.dtype_code(mc),
                                                   _lib.stream_ptr(dev))
         _lib.check(rc, "vmf_s1_projnormal_bwd")
-        return dm, dk.view(kshape), None, None, None
+        return dm, dk.view(kshape), None, None, None, None
 
 
 def s1_reparameterize(mean_vec, kappa, noise=None):
     """z = F.normalize(mean_vec * kappa + noise, p=2, dim=1)  (regular_cnn/s1_vae.py:48-55)"""
     if noise is None and rng.rng_mode() == "torch":
         noise = torch.randn_like(mean_vec)  # the reference's draw (:51)
-    seed, offset = (0, 0) if noise is not None else rng.default_generator.next_offset()
-    return _S1ProjNormal.apply(mean_vec, kappa, noise, seed, offset)
+    seed, offset, offset_dev = (0, 0, None) if noise is not None else rng.default_generator.ticket(mean_vec.device)
+    return _S1ProjNormal.apply(mean_vec, kappa, noise, seed, offset, offset_dev)
 
 
 class S1_VAE(nn.Module):

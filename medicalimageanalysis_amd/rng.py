@@ -8,34 +8,79 @@ global row offset) reproduces the unsharded draw bit for bit.
 import os
 import threading
 
+import torch
+
 
 class PhiloxGenerator:
     def __init__(self, seed=0x5EED, offset=0):
         self._lock = threading.Lock()
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.offset = int(offset) & 0xFFFFFFFFFFFFFFFF
+        self._dev_counter = None
 
     def manual_seed(self, seed):
         with self._lock:
             self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
             self.offset = 0
+            if self._dev_counter is not None:
+                self._dev_counter.zero_()
         return self
 
     def next_offset(self):
         """Offset for one sampling call (all ranks of a sharded job must make the same calls in the same order)."""
+        if self._dev_counter is not None:
+            raise RuntimeError("this generator keeps its counter on the device: use ticket(device)")
+        seed, o, _ = self.ticket(None)
+        return seed, o
+
+    # ---- device-resident counter (HIP graphs) ----------------------------------------------------------------
+    def enable_device_counter(self, device):
+        """Move the call counter into device memory.  The host arguments of a launch captured into a HIP graph are
+        frozen, so a host counter would replay the same noise forever; with the counter on the device each call
+        reads it (a one-element snapshot kept for the backward pass) and advances it with stream-ordered
+        operations that are captured too, so every replay draws fresh noise.  The draws are the same as with the
+        host counter.  Call this BEFORE capture (memory allocated during capture belongs to the graph)."""
+        device = torch.device(device)
         with self._lock:
-            o = self.offset
-            self.offset = (self.offset + 1) & 0xFFFFFFFFFFFFFFFF
-        return self.seed, o
+            if self._dev_counter is None:
+                self._dev_counter = torch.tensor([self._as_i64(self.offset)], dtype=torch.int64, device=device)
+            elif self._dev_counter.device != device:
+                raise RuntimeError(f"the counter already lives on {self._dev_counter.device}")
+        return self
+
+    @staticmethod
+    def _as_i64(u):
+        return u - (1 << 64) if u >= (1 << 63) else u
+
+    def ticket(self, device):
+        """(seed, host_offset, device_offset_tensor_or_None) for one sampling call; the kernels use
+        host_offset + device_offset[0]."""
+        with self._lock:
+            if self._dev_counter is None:
+                if device is not None and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError(
+                        "in-kernel noise under HIP graph capture needs a device-resident counter (a captured host "
+                        "offset would replay identical noise): call generator.enable_device_counter(device) before "
+                        "capturing, or draw the noise with torch (VMF_RNG=torch)")
+                o = self.offset
+                self.offset = (self.offset + 1) & 0xFFFFFFFFFFFFFFFF
+                return self.seed, o, None
+            snap = self._dev_counter.clone()
+            self._dev_counter.add_(1)
+            return self.seed, 0, snap
 
     def get_state(self):
         with self._lock:
+            if self._dev_counter is not None:  # synchronises
+                self.offset = int(self._dev_counter.item()) & 0xFFFFFFFFFFFFFFFF
             return {"seed": self.seed, "offset": self.offset}
 
     def set_state(self, state):
         with self._lock:
             self.seed = int(state["seed"]) & 0xFFFFFFFFFFFFFFFF
             self.offset = int(state["offset"]) & 0xFFFFFFFFFFFFFFFF
+            if self._dev_counter is not None:
+                self._dev_counter.fill_(self._as_i64(self.offset))
 
 
 default_generator = PhiloxGenerator()

@@ -15,11 +15,12 @@ def _sphere_sample(shape_rows, dim, device, dtype, gauss=None, row0=0, generator
         n *= int(s)
     out = torch.empty(tuple(shape_rows) + (dim,), device=device, dtype=dtype)
     dev = _lib.require_hip(out, gauss)
-    seed, offset = (0, 0)
+    seed, offset, offset_dev = (0, 0, None)
     if gauss is None:
-        seed, offset = (generator or rng.default_generator).next_offset()
+        seed, offset, offset_dev = (generator or rng.default_generator).ticket(dev)
     with torch.cuda.device(dev):
         rc = _lib.lib().vmf_sphere_uniform_sample(_lib.ptr(gauss), _lib.ptr(out), n, dim, row0, seed, offset,
+                                                  _lib.ptr(offset_dev),
                                                   _lib.dtype_code(out), _lib.stream_ptr(dev))
     _lib.check(rc, "vmf_sphere_uniform_sample")
     return out

@@ -63,9 +63,17 @@ def _numel(shape):
     return n
 
 
+def _capture_safe(validate_args, t):
+    """Distribution's argument check (`scale > 0`) reads its result on the host; a stream that is being captured
+    into a HIP graph cannot synchronise, so the default check is skipped there (an explicit True is kept)."""
+    if validate_args is None and t.is_cuda and torch.cuda.is_current_stream_capturing():
+        return False
+    return validate_args
+
+
 class _VMF3RSample(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, loc, scale, u, eps, plan, seed, offset):
+    def forward(ctx, loc, scale, u, eps, plan, seed, offset, offset_dev=None):
         dev = _lib.require_hip(loc, scale, u, eps)
         locc, scalec = loc.detach().contiguous(), scale.detach().contiguous()
         uc = None if u is None else u.contiguous()
@@ -77,10 +85,10 @@ class _VMF3RSample(torch.autograd.Function):
                     _lib.ptr(locc), _lib.ptr(scalec), _lib.ptr(uc), _lib.ptr(epsc), _lib.ptr(z), None,
                     len(plan["odims"]), _lib.i64_array(plan["odims"]), _lib.i64_array(plan["w_str"]),
                     _lib.i64_array(plan["k_str"]), _lib.i64_array(plan["l_str"]), _lib.i64_array(plan["e_str"]),
-                    _lib.dtype_code(loc), seed, offset, _lib.stream_ptr(dev))
+                    _lib.dtype_code(loc), seed, offset, _lib.ptr(offset_dev), _lib.stream_ptr(dev))
             _lib.check(rc, "vmf3_rsample_fwd")
         ctx.save_for_backward(locc, scalec, uc, epsc)
-        ctx.plan, ctx.seed, ctx.offset = plan, seed, offset
+        ctx.plan, ctx.seed, ctx.offset, ctx.offset_dev = plan, seed, offset, offset_dev
         ctx.loc_shape, ctx.scale_shape = loc.shape, scale.shape
         return z
 
@@ -98,9 +106,9 @@ class _VMF3RSample(torch.autograd.Function):
                     _lib.ptr(dscale), locc.numel() // 3, scalec.numel(), len(plan["odims"]),
                     _lib.i64_array(plan["odims"]), _lib.i64_array(plan["w_str"]), _lib.i64_array(plan["k_str"]),
                     _lib.i64_array(plan["l_str"]), _lib.i64_array(plan["e_str"]), _lib.dtype_code(locc), ctx.seed,
-                    ctx.offset, _lib.stream_ptr(dev))
+                    ctx.offset, _lib.ptr(ctx.offset_dev), _lib.stream_ptr(dev))
             _lib.check(rc, "vmf3_rsample_bwd")
-        return dloc.view(ctx.loc_shape), dscale.view(ctx.scale_shape), None, None, None, None, None
+        return dloc.view(ctx.loc_shape), dscale.view(ctx.scale_shape), None, None, None, None, None, None
 
 
 class VonMisesFisher3D(Distribution):
@@ -129,7 +137,7 @@ class VonMisesFisher3D(Distribution):
         self.scale = scale
         self.device = loc.device
         self.dtype = loc.dtype
-        super().__init__(batch_shape=loc.shape[:-1], validate_args=validate_args)
+        super().__init__(batch_shape=loc.shape[:-1], validate_args=_capture_safe(validate_args, loc))
 
     @property
     def loc(self):
@@ -161,11 +169,11 @@ class VonMisesFisher3D(Distribution):
         if rng.rng_mode() == "torch":
             u = torch.rand(plan["w_shape"], device=self.device, dtype=self.dtype)         # :56
             eps = torch.randn(plan["e_shape"] + (3,), device=self.device, dtype=self.dtype)  # :75
-            seed = offset = 0
+            seed, offset, offset_dev = 0, 0, None
         else:
             u = eps = None
-            seed, offset = rng.default_generator.next_offset()
-        return _VMF3RSample.apply(loc, scale, u, eps, plan, seed, offset)
+            seed, offset, offset_dev = rng.default_generator.ticket(loc.device)
+        return _VMF3RSample.apply(loc, scale, u, eps, plan, seed, offset, offset_dev)
 
     def rsample_with_noise(self, u, eps, sample_shape=torch.Size()):
         """rsample with the caller's noise: u of shape sample_shape + scale.shape (uniform), eps of shape
@@ -250,7 +258,7 @@ class VonMisesFisher3DLogProb(VonMisesFisher3D):
 # ---- general m ---------------------------------------------------------------------------------------------
 class _VMFRSample(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mu, kappa, n, mu_stride, kappa_stride, max_prop, row0, seed, offset, want_logp):
+    def forward(ctx, mu, kappa, n, mu_stride, kappa_stride, max_prop, row0, seed, offset, want_logp, offset_dev=None):
         dev = _lib.require_hip(mu, kappa)
         m = mu.shape[-1]
         muc, kc = mu.detach().contiguous(), kappa.detach().contiguous()
@@ -261,11 +269,12 @@ class _VMFRSample(torch.autograd.Function):
         with torch.cuda.device(dev):
             rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(muc), mu_stride, _lib.ptr(kc), kappa_stride, _lib.ptr(z),
                                             _lib.ptr(w), _lib.ptr(omw), None, _lib.ptr(logp), n, m, None, None, 0,
-                                            None, max_prop, row0, seed, offset, _lib.dtype_code(muc),
+                                            None, max_prop, row0, seed, offset, _lib.ptr(offset_dev), _lib.dtype_code(muc),
                                             _lib.stream_ptr(dev))
         _lib.check(rc, "vmf_rsample_fwd")
         ctx.save_for_backward(muc, kc, w, omw)
         ctx.meta = (n, m, mu_stride, kappa_stride, row0, seed, offset, mu.shape, kappa.shape)
+        ctx.offset_dev = offset_dev
         if want_logp:
             ctx.mark_non_differentiable(logp)
             return z, logp
@@ -282,13 +291,14 @@ class _VMFRSample(torch.autograd.Function):
         with torch.cuda.device(dev):
             rc = _lib.lib().vmf_rsample_bwd(_lib.ptr(muc), mu_stride, _lib.ptr(kc), kappa_stride, _lib.ptr(w),
                                             _lib.ptr(omw), _lib.ptr(gzc), None, _lib.ptr(dmu), _lib.ptr(dk), n, m,
-                                            row0, seed, offset, _lib.dtype_code(muc), _lib.stream_ptr(dev))
+                                            row0, seed, offset, _lib.ptr(ctx.offset_dev), _lib.dtype_code(muc),
+                                            _lib.stream_ptr(dev))
         _lib.check(rc, "vmf_rsample_bwd")
         if mu_stride == 0:
             dmu = dmu.sum(0, keepdim=True)
         if kappa_stride == 0:
             dk = dk.sum(0, keepdim=True)
-        return (dmu.view(mu_shape), dk.view(k_shape)) + (None,) * 8
+        return (dmu.view(mu_shape), dk.view(k_shape)) + (None,) * 9
 
 
 class _VMFLogProb(torch.autograd.Function):
@@ -364,7 +374,8 @@ class VonMisesFisher(Distribution):
         self.max_proposals = int(max_proposals)
         self.row_offset = int(row_offset)
         self.generator = generator or rng.default_generator
-        super().__init__(batch_shape=loc.shape[:-1], event_shape=loc.shape[-1:], validate_args=validate_args)
+        super().__init__(batch_shape=loc.shape[:-1], event_shape=loc.shape[-1:],
+                         validate_args=_capture_safe(validate_args, loc))
 
     def _kappa_rows(self):
         k = self.scale.to(self.dtype)
@@ -385,13 +396,13 @@ class VonMisesFisher(Distribution):
             if S > 1:
                 mu2d = mu2d.unsqueeze(0).expand(S, nb, self.m).reshape(n, self.m)
                 kap = kap.unsqueeze(0).expand(S, nb).reshape(n)
-        seed, offset = self.generator.next_offset()
+        seed, offset, offset_dev = self.generator.ticket(self.device)
         out_shape = tuple(sample_shape) + tuple(self.batch_shape)
         if n == 0:
             z = torch.empty(out_shape + (self.m,), device=self.device, dtype=self.dtype)
             return (z, z.new_empty(out_shape)) if return_log_prob else z
         res = _VMFRSample.apply(mu2d, kap, n, mu_stride, kappa_stride, self.max_proposals, self.row_offset, seed,
-                                offset, bool(return_log_prob))
+                                offset, bool(return_log_prob), offset_dev)
         if return_log_prob:
             z, logp = res
             return z.view(out_shape + (self.m,)), logp.view(out_shape)

@@ -71,7 +71,7 @@ def close_vmf3(z, z_ref, tag, loc, scale, u, eps, ss=()):
 
 def test_library_loaded_is_in_tree():
     assert os.path.dirname(_lib.library_path()).endswith("medicalimageanalysis_amd")
-    assert _lib.lib().vmf_version() == 100
+    assert _lib.lib().vmf_version() == 110
 
 
 # ---- VonMisesFisher3D ---------------------------------------------------------------------------------------
@@ -350,7 +350,7 @@ def _call_rsample_pre(mu, kappa, pe, pu, ga, dtype):
     idx = torch.empty(n, device=DEV, dtype=torch.int32)
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(tmu), m, _lib.ptr(tk), 1, _lib.ptr(z), _lib.ptr(w), None,
                                     C.c_void_p(idx.data_ptr()), None, n, m, _lib.ptr(tpe), _lib.ptr(tpu), pe.shape[1],
-                                    _lib.ptr(tga), 0, 0, 0, 0, _lib.dtype_code(z), _lib.stream_ptr(DEV))
+                                    _lib.ptr(tga), 0, 0, 0, 0, None, _lib.dtype_code(z), _lib.stream_ptr(DEV))
     _lib.check(rc, "vmf_rsample_fwd")
     torch.cuda.synchronize()
     return N(z), N(w), N(idx)
@@ -394,7 +394,7 @@ def test_general_rsample_philox_vs_oracle(oracle, tag, m, n):
     w = torch.empty(n, device=DEV, dtype=TD[tag])
     idx = torch.empty(n, device=DEV, dtype=torch.int32)
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(tmu), m, _lib.ptr(tk), 1, _lib.ptr(z), _lib.ptr(w), None,
-                                    C.c_void_p(idx.data_ptr()), None, n, m, None, None, 0, None, 64, row0, seed, off,
+                                    C.c_void_p(idx.data_ptr()), None, n, m, None, None, 0, None, 64, row0, seed, off, None,
                                     _lib.dtype_code(z), _lib.stream_ptr(DEV))
     _lib.check(rc, "vmf_rsample_fwd")
     z, w, idx = N(z), N(w), N(idx)
@@ -409,7 +409,7 @@ def test_general_rsample_philox_vs_oracle(oracle, tag, m, n):
     z2 = torch.empty((b - a, m), device=DEV, dtype=TD[tag])
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(tmu[a:b].contiguous()), m, _lib.ptr(tk[a:b].contiguous()), 1,
                                     _lib.ptr(z2), None, None, None, None, b - a, m, None, None, 0, None, 64, row0 + a,
-                                    seed, off, _lib.dtype_code(z2), _lib.stream_ptr(DEV))
+                                    seed, off, None, _lib.dtype_code(z2), _lib.stream_ptr(DEV))
     _lib.check(rc, "vmf_rsample_fwd shard")
     assert np.array_equal(N(z2), z[a:b])
 
@@ -446,7 +446,7 @@ def test_general_rsample_full_size_properties():
     w = torch.empty(n, device=DEV)
     idx = torch.empty(n, device=DEV, dtype=torch.int32)
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(z), _lib.ptr(w), None,
-                                    C.c_void_p(idx.data_ptr()), None, n, m, None, None, 0, None, 64, 0, 99, 0,
+                                    C.c_void_p(idx.data_ptr()), None, n, m, None, None, 0, None, 64, 0, 99, 0, None,
                                     _lib.VMF_F32, _lib.stream_ptr(DEV))
     _lib.check(rc, "vmf_rsample_fwd")
     assert float((z.norm(dim=-1) - 1).abs().max()) < 1e-4
@@ -459,7 +459,7 @@ def test_general_rsample_full_size_properties():
     a = n - 1000
     z2 = torch.empty((1000, m), device=DEV)
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(mu[a:]), m, _lib.ptr(kappa[a:]), 1, _lib.ptr(z2), None, None, None, None,
-                                    1000, m, None, None, 0, None, 64, a, 99, 0, _lib.VMF_F32, _lib.stream_ptr(DEV))
+                                    1000, m, None, None, 0, None, 64, a, 99, 0, None, _lib.VMF_F32, _lib.stream_ptr(DEV))
     _lib.check(rc, "vmf_rsample_fwd")
     assert torch.equal(z2, z[a:])
 
@@ -555,7 +555,7 @@ def test_spherical_vae_train_step_batch128():
     loss_ref = cfg["gamma"] * torch.mean((x - x_mu_ref) ** 2) + cfg["beta"] * kl.mean()
     loss_ref.backward()
     np.testing.assert_allclose(N(z), N(z_ref), rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(float(loss), float(loss_ref), rtol=1e-5)
+    np.testing.assert_allclose(float(loss.detach()), float(loss_ref.detach()), rtol=1e-5)
     for (name, a), (_, b) in zip(model.named_parameters(), ref.named_parameters()):
         scale = float(b.grad.abs().max()) + 1e-12
         np.testing.assert_allclose(N(a.grad), N(b.grad), rtol=2e-3, atol=2e-3 * scale, err_msg=name)
@@ -590,13 +590,13 @@ def test_general_backward_vs_autograd_of_restated_forward(m):
     omw = torch.empty(n, device=DEV, dtype=torch.float64)
     mud, kd = mu.detach().contiguous(), kappa.detach().contiguous()
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(mud), m, _lib.ptr(kd), 1, _lib.ptr(zk), _lib.ptr(w), _lib.ptr(omw), None,
-                                    None, n, m, _lib.ptr(pe), _lib.ptr(pu), 4, _lib.ptr(ga), 0, 0, 0, 0, _lib.VMF_F64,
+                                    None, n, m, _lib.ptr(pe), _lib.ptr(pu), 4, _lib.ptr(ga), 0, 0, 0, 0, None, _lib.VMF_F64,
                                     _lib.stream_ptr(DEV))
     _lib.check(rc, "fwd")
     dmu = torch.empty_like(mud)
     dk = torch.empty_like(kd)
     rc = _lib.lib().vmf_rsample_bwd(_lib.ptr(mud), m, _lib.ptr(kd), 1, _lib.ptr(w), _lib.ptr(omw), _lib.ptr(c),
-                                    _lib.ptr(ga), _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 0, 0, _lib.VMF_F64,
+                                    _lib.ptr(ga), _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 0, 0, None, _lib.VMF_F64,
                                     _lib.stream_ptr(DEV))
     _lib.check(rc, "bwd")
     mu2, k2 = mud.clone().requires_grad_(), kd.clone().requires_grad_()
@@ -831,42 +831,134 @@ def test_hyperspherical_vae_s9_trains():
         loss.backward()
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] < 0.9 * losses[0], losses[::5]
     np.testing.assert_allclose(N(z.norm(dim=-1)), 1.0, atol=1e-5)
 
 
 def test_entry_points_are_graph_capturable():
-    """the library neither allocates nor synchronises, so its launches can be captured into a HIP graph and replayed"""
+    """the library neither allocates nor synchronises, so its launches can be captured into a HIP graph and replayed;
+    with the Philox call counter on the device every replay draws the noise the next eager call would have drawn"""
     loc = torch.randn(256, 3, device=DEV)
     kap = torch.rand(256, device=DEV) * 50 + 1
     u = torch.rand(256, device=DEV)
     eps = torch.randn(256, 3, device=DEV)
-    mu = torch.nn.functional.normalize(torch.randn(512, 64, device=DEV), dim=-1)
-    k64 = torch.rand(512, device=DEV) * 100 + 1
+    mu = torch.nn.functional.normalize(torch.randn(512, 64, device=DEV), dim=-1).requires_grad_()
+    k64 = (torch.rand(512, device=DEV) * 100 + 1).requires_grad_()
+    c = torch.randn(512, 64, device=DEV)
     q3 = VonMisesFisher3D(loc, kap, validate_args=False)
-    qm = VonMisesFisher(mu, k64, validate_args=False, generator=rng.PhiloxGenerator(5, 0))
+    gen = rng.PhiloxGenerator(5, 0).enable_device_counter(DEV)
+    qm = VonMisesFisher(mu, k64, validate_args=False, generator=gen)
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):  # warm-up outside capture
+    with torch.cuda.stream(s):  # warm-up outside capture (takes offset 0)
         q3.rsample_with_noise(u, eps)
         klmod.kl_mean(kap, "spherical")
+        (qm.rsample() * c).sum().backward()
     torch.cuda.current_stream().wait_stream(s)
+    mu.grad = k64.grad = None
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         z3 = q3.rsample_with_noise(u, eps)
         klm = klmod.kl_mean(kap, "spherical")
         zm = qm.rsample()
-    g.replay()
-    torch.cuda.synchronize()
+        (zm * c).sum().backward()
+    assert gen.get_state()["offset"] == 1          # capture records, it does not run
+    for replay in (1, 2, 3):
+        g.replay()
+        torch.cuda.synchronize()
+        mu2, k2 = mu.detach().clone().requires_grad_(), k64.detach().clone().requires_grad_()
+        ref = VonMisesFisher(mu2, k2, validate_args=False, generator=rng.PhiloxGenerator(5, replay)).rsample()
+        (ref * c).sum().backward()
+        assert torch.equal(zm, ref), replay
+        # .grad was None at capture, so the captured backward writes (not accumulates) the static .grad tensors
+        np.testing.assert_allclose(N(mu.grad), N(mu2.grad), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(N(k64.grad), N(k2.grad), rtol=1e-5, atol=1e-6)
+        assert gen.get_state()["offset"] == 1 + replay
     ref3 = q3.rsample_with_noise(u, eps)
-    refm = VonMisesFisher(mu, k64, validate_args=False, generator=rng.PhiloxGenerator(5, 0)).rsample()
-    assert torch.equal(z3, ref3) and torch.equal(zm, refm)
+    assert torch.equal(z3, ref3)
     assert abs(float(klm) - float(klmod.kl_mean(kap, "spherical"))) < 1e-6
     u.copy_(torch.rand(256, device=DEV))  # new inputs in place, replay recomputes
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(z3, q3.rsample_with_noise(u, eps))
+
+
+def test_host_counter_refuses_capture():
+    gen = rng.PhiloxGenerator(1, 0)
+    with mock.patch("torch.cuda.is_current_stream_capturing", return_value=True):
+        with pytest.raises(RuntimeError, match="enable_device_counter"):
+            gen.ticket(DEV)
+    gen.enable_device_counter(DEV)
+    with pytest.raises(RuntimeError):
+        gen.next_offset()
+    with mock.patch("torch.cuda.is_current_stream_capturing", return_value=True):
+        seed, off, dev_off = gen.ticket(DEV)
+    assert (seed, off) == (1, 0) and int(dev_off.item()) == 0 and gen.get_state()["offset"] == 1
+    gen.set_state({"seed": 3, "offset": (1 << 64) - 1})       # wraps like the host counter
+    assert gen.ticket(DEV)[2].item() == -1 and gen.get_state()["offset"] == 0
+
+
+def test_device_counter_draws_equal_host_counter_draws():
+    mu = torch.nn.functional.normalize(torch.randn(300, 10, device=DEV, dtype=torch.float64), dim=-1)
+    kap = torch.rand(300, device=DEV, dtype=torch.float64) * 50 + 1
+    ga = rng.PhiloxGenerator(9, (1 << 32) - 1)                 # crosses the 32-bit boundary of the counter word
+    gb = rng.PhiloxGenerator(9, (1 << 32) - 1).enable_device_counter(DEV)
+    for _ in range(3):
+        a = VonMisesFisher(mu, kap, validate_args=False, generator=ga).rsample()
+        b = VonMisesFisher(mu, kap, validate_args=False, generator=gb).rsample()
+        assert torch.equal(a, b)
+    sa = HypersphericalUniform(9, device=DEV).sample((64,), generator=ga)
+    sb = HypersphericalUniform(9, device=DEV).sample((64,), generator=gb)
+    assert torch.equal(sa, sb)
+
+
+def test_graphed_train_step_matches_eager_steps():
+    """forward + ELBO + backward + Adam as ONE graph launch; with in-kernel noise on a device counter the graphed
+    run and the eager run make identical draws, so their losses agree step by step"""
+    from medicalimageanalysis_amd.graph import GraphedTrainStep
+    cfg = dict(extrinsic_dim=784, latent_dim=3, sftbeta=1.0, encoder_width=64, encoder_depth=2, decoder_width=64,
+               decoder_depth=2, dropout_p=0.0, device="cuda", gamma=1.0, beta=0.01)
+    x = torch.rand(128, 784, device=DEV)
+
+    def loss_fn(model, xb):
+        z, x_mu, params = model(xb)
+        return model._elbo(xb, x_mu, params)
+
+    def run(graphed, steps=6):
+        torch.manual_seed(0)
+        model = SphericalVAE(cfg)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+        rng.default_generator.set_state({"seed": 77, "offset": 0})
+        out = []
+        if graphed:
+            step = GraphedTrainStep(model, opt, loss_fn, [x], warmup=2)
+            for _ in range(steps - 2):
+                out.append(float(step(x)))
+        else:
+            for i in range(steps):
+                opt.zero_grad(set_to_none=True)
+                loss = loss_fn(model, x)
+                loss.backward()
+                opt.step()
+                if i >= 2:
+                    out.append(float(loss.detach()))
+        return out
+
+    with mock.patch.dict(os.environ, {"VMF_RNG": "philox"}):
+        old = rng.default_generator
+        try:
+            rng.default_generator = rng.PhiloxGenerator()
+            eager = run(False)
+            rng.default_generator = rng.PhiloxGenerator()
+            graphed = run(True)
+        finally:
+            rng.default_generator = old
+    np.testing.assert_allclose(graphed, eager, rtol=2e-4)
+    assert graphed[-1] < graphed[0]
+    with pytest.raises(ValueError, match="capturable"):
+        m2 = SphericalVAE(cfg)
+        GraphedTrainStep(m2, torch.optim.Adam(m2.parameters()), loss_fn, [x])
 
 
 def test_error_conventions():
@@ -882,7 +974,7 @@ def test_error_conventions():
     z = VonMisesFisher3D(torch.randn(0, 3, device=DEV), torch.ones(0, device=DEV)).rsample()
     assert z.shape == (0, 3)
     rc = _lib.lib().vmf_rsample_fwd(None, 64, None, 1, None, None, None, None, None, 10, 64, None, None, 0, None, 64, 0,
-                                    0, 0, 0, None)
+                                    0, 0, None, 0, None)
     assert rc == -1 and b"null" in _lib.lib().vmf_last_error_string()
     rc = _lib.lib().vmf_ive_fwd(0.5, _lib.ptr(loc), _lib.ptr(loc), 4, 7, None)
     assert rc == -2
