@@ -11,6 +11,7 @@
 
 #include "common.h"
 #include "debye_coeffs.h"
+#include "i0e_coeffs.h"
 
 #define VMF_DEBYE_R2 900.0
 #define VMF_AMOS_LIMIT 1073741823.5
@@ -80,6 +81,27 @@ VMF_HD double log_ive_pos(double v, double lgam_v1, double x) {
 }
 
 // ive(v, z) with scipy's edge conventions (see include/vmf_hip.h)
+// Orders 0 and 1: Chebyshev expansions on [0, 8] and [8, inf) (tables in i0e_coeffs.h), ~30 fused multiply-adds each
+// instead of a power series of up to 60 terms.  Clenshaw recurrence; x >= 0.
+VMF_HD double cheb_sum(const double* c, int n, double t) {
+  double b0 = 0.0, b1 = 0.0;
+  const double t2 = 2.0 * t;
+  for (int k = n - 1; k >= 1; --k) {
+    const double b = c[k] + t2 * b0 - b1;
+    b1 = b0;
+    b0 = b;
+  }
+  return c[0] + t * b0 - b1;
+}
+VMF_HD double i0e_pos(double x) {
+  if (x <= 8.0) return cheb_sum(I0E_A, I0E_A_N, 0.25 * x - 1.0);
+  return cheb_sum(I0E_B, I0E_B_N, 16.0 / x - 1.0) / ::sqrt(x);
+}
+VMF_HD double i1e_pos(double x) {
+  if (x <= 8.0) return x * cheb_sum(I1E_A, I1E_A_N, 0.25 * x - 1.0);
+  return cheb_sum(I1E_B, I1E_B_N, 16.0 / x - 1.0) / ::sqrt(x);
+}
+
 VMF_HD double ive_eval(const BesselOrder& o, double z) {
   if (z != z) return z;
   if (o.unsupported) return NAN;
@@ -92,6 +114,7 @@ VMF_HD double ive_eval(const BesselOrder& o, double z) {
   if (x == 0) return o.is_int ? (v == 0 ? 1.0 : 0.0) : (v < 0 ? NAN : 0.0);
   if (o.amos && x > VMF_AMOS_LIMIT) return NAN;
   if (isinf(x)) return 0.0;
+  if (o.is_int && v <= 1.0) return sign * (v == 0.0 ? i0e_pos(x) : i1e_pos(x));
   if (o.neg_frac && x > 20.0) {
     // I_v = I_{-v} + (2/pi) sin(-v pi) K_{-v}; the K term is < 2 e^{-2x} relative: below one ulp here
     return ::exp(log_ive_pos(o.av, o.lgam_av1, x));

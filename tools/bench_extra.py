@@ -152,6 +152,74 @@ def main():
     print(f"| SphericalVAE train step B=128 (z 128x128x3): this package | {ms_a:.3f} | - | {1e3 / ms_a:.0f} steps/s |")
     print(f"| same step with the sampler/KL as torch ops (reference formulas) | {ms_b:.3f} | - | {1e3 / ms_b:.0f} steps/s |")
 
+    # --- the same step captured as one HIP graph (forward + ELBO + backward + Adam = one launch)
+    from medicalimageanalysis_amd.graph import GraphedTrainStep
+    torch.manual_seed(0)
+    model_g = SphericalVAE(cfg)
+    opt_g = torch.optim.Adam(model_g.parameters(), lr=1e-3, capturable=True)
+
+    def loss_fn(mdl, xb):
+        z, x_mu, params = mdl(xb)
+        return mdl._elbo(xb, x_mu, params)
+    for mode in ("torch", "philox"):
+        os.environ["VMF_RNG"] = mode
+        gstep = GraphedTrainStep(model_g, opt_g, loss_fn, [x])
+        ms_g = timeit(lambda: gstep(x), reps=30, warm=5)
+        print(f"| same step as one HIP graph ({mode} noise) | {ms_g:.3f} | - | {1e3 / ms_g:.0f} steps/s |")
+    os.environ["VMF_RNG"] = "torch"
+
+    # --- consumers: fused ELBO on the (128, 128, 784) decoder output, torus embedding, latent losses
+    from medicalimageanalysis_amd import losses
+    B, D = 128, 784
+    xh = torch.rand(B, B, D, device=DEV, requires_grad=True)
+    kp = (torch.rand(B, 1, device=DEV) * 50 + 1).requires_grad_()
+    ms = timeit(lambda: losses.elbo_loss(x, xh, kp, 1.0, 0.01, "spherical"))
+    row("fused ELBO fwd (128,128,784) fp32 (incl. python)", ms, xh.numel() * 4, xh.numel(), "elems")
+    ms_t = timeit(lambda: torch.mean((x - xh) * (x - xh)) + 0.01 * klmod.kl_mean(kp, "spherical"))
+    row("  same with torch ops for the MSE", ms_t, xh.numel() * 4, xh.numel(), "elems")
+    lo = losses.elbo_loss(x, xh, kp, 1.0, 0.01, "spherical")
+
+    def eb():
+        xh.grad = None
+        lo.backward(retain_graph=True)
+    ms = timeit(eb)
+    row("fused ELBO bwd (128,128,784) fp32 (incl. python)", ms, xh.numel() * 8, xh.numel(), "elems")
+    n = 1 << 24
+    zt = torch.nn.functional.normalize(torch.randn(n, 3, device=DEV, generator=g), dim=-1)
+    zp = torch.nn.functional.normalize(torch.randn(n, 3, device=DEV, generator=g), dim=-1)
+    ms = timeit(lambda: losses.build_torus(zt, zp, 1.5, 0.5))
+    row("build_torus n=2^24 fp32", ms, n * 36, n, "rows")
+    labels = torch.rand(4096, 2, device=DEV) * 3
+    for ds in ("S1_dataset", "S2_dataset", "T2_dataset"):
+        c = {"dataset": ds, "longest_radius": 1.5, "shortest_radius": 0.5}
+        ms = timeit(lambda: losses.latent_loss(labels, zt.view(-1, 4096, 3), c))
+        row(f"latent_loss {ds} n=2^24 fp32", ms, n * 12, n, "rows")
+    del zt, zp, xh
+    torch.cuda.empty_cache()
+
+    # --- product of circles T^16: 2^23 rows x 16 circles = 2^27 vMF(m=2) draws; S^1 projected normal + I1/I0 KL
+    n = 1 << 27
+    mu = torch.nn.functional.normalize(torch.randn(n, 2, device=DEV, generator=g), dim=-1)
+    kap = torch.exp(torch.rand(n, device=DEV, generator=g) * np.log(1e3))
+    z = torch.empty_like(mu)
+
+    def f5():
+        rc = lib.vmf_rsample_fwd(_lib.ptr(mu), 2, _lib.ptr(kap), 1, _lib.ptr(z), None, None, None, None, n, 2, None, None,
+                                 0, None, 64, 0, 1, 0, None, _lib.VMF_F32, sp)
+        assert rc == 0
+    ms = timeit(f5, reps=5, warm=2)
+    row("T^16: vMF m=2, 2^23 x 16 circles fp32", ms, n * 20, n, "circle draws")
+
+    def f6():
+        rc = lib.vmf_s1_projnormal_fwd(_lib.ptr(mu), _lib.ptr(kap), None, _lib.ptr(z), n, 2, 0, 1, 0, None, _lib.VMF_F32, sp)
+        assert rc == 0
+    ms = timeit(f6, reps=5, warm=2)
+    row("S^1 projected normal 2^27 rows fp32", ms, n * 20, n, "rows")
+    ms = timeit(lambda: klmod.kl_sum(kap, "s1"), reps=5, warm=2)
+    row("KL sum (S^1, I1/I0) 2^27 fp32", ms, n * 4, n, "elems")
+    del mu, kap, z
+    torch.cuda.empty_cache()
+
     # --- ive
     n = 1 << 24
     x = torch.exp(torch.rand(n, device=DEV, generator=g, dtype=torch.float64) * np.log(1e5))
