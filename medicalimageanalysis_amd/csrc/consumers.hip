@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void elbo_fwd_kernel(const T* __restrict__ x, 
   }
   for (int64_t i = tid; i < n_kappa; i += nthreads) {
     T g;
-    acc_kl += (double)kl_value<T>(kappa[i], variant, kb, &g);
+    acc_kl += (double)kl_eval<T>(kappa[i], variant, kb, &g);
   }
   double t0 = block_sum_double(acc_rec, red);
   __syncthreads();
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void elbo_bwd_kernel(const T* __restrict__ x, 
     const T c = a_kl * go;
     for (int64_t i = tid; i < n_kappa; i += nthreads) {
       T g;
-      kl_value<T>(kappa[i], variant, kb, &g);
+      kl_eval<T>(kappa[i], variant, kb, &g);
       d_kappa[i] = c * g;
     }
   }

@@ -102,16 +102,31 @@ extern "C" int vmf_bessel_ratio_fwd(double v, const void* z, void* out, int64_t 
 // ---- KL ------------------------------------------------------------------------------------------------
 // Replaces the boolean-mask gather/scatter and the two `.any()` host syncs of
 // model/spherical_vae.py:153-182 with one pass; the `.mean()` of :134 is the fused two-stage sum.
-template <typename T>
+// VEC = 4: 128-bit loads / stores of four consecutive elements per lane (fp32, 16-byte aligned); the n % 4 tail is
+// taken by the first lanes with scalar accesses.
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void kl_fwd_kernel(const T* __restrict__ kappa, T* __restrict__ out,
                                                      double* __restrict__ partial, int64_t n, int variant,
                                                      KlBessel kb) {
   __shared__ double red[4];
   double acc = 0;
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t nvec = VEC == 4 ? n / 4 : 0;
+  for (int64_t i = tid; i < nvec; i += stride) {
+    const Vec4<T> k4 = *reinterpret_cast<const Vec4<T>*>(kappa + 4 * i);
+    Vec4<T> o4;
     T g;
-    T kl = kl_value<T>(kappa[i], variant, kb, &g);
+    o4.v[0] = kl_eval<T>(k4.v[0], variant, kb, &g);
+    o4.v[1] = kl_eval<T>(k4.v[1], variant, kb, &g);
+    o4.v[2] = kl_eval<T>(k4.v[2], variant, kb, &g);
+    o4.v[3] = kl_eval<T>(k4.v[3], variant, kb, &g);
+    if (out) *reinterpret_cast<Vec4<T>*>(out + 4 * i) = o4;
+    acc += ((double)o4.v[0] + (double)o4.v[1]) + ((double)o4.v[2] + (double)o4.v[3]);
+  }
+  for (int64_t i = 4 * nvec + tid; i < n; i += stride) {
+    T g;
+    T kl = kl_eval<T>(kappa[i], variant, kb, &g);
     if (out) out[i] = kl;
     acc += (double)kl;
   }
@@ -130,17 +145,34 @@ __global__ __launch_bounds__(256) void kl_final_kernel(const double* __restrict_
   if (threadIdx.x == 0) *sum_out = alpha * t;
 }
 
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void kl_bwd_kernel(const T* __restrict__ kappa, const T* __restrict__ gout,
                                                      int64_t gstride, T gscale, T* __restrict__ dkappa, int64_t n,
                                                      int variant, KlBessel kb) {
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t nvec = VEC == 4 ? n / 4 : 0;
+  for (int64_t i = tid; i < nvec; i += stride) {
+    const Vec4<T> k4 = *reinterpret_cast<const Vec4<T>*>(kappa + 4 * i);
+    Vec4<T> go;
+    if (gstride) go = *reinterpret_cast<const Vec4<T>*>(gout + 4 * i);
+    else go.v[0] = go.v[1] = go.v[2] = go.v[3] = gout[0];
+    Vec4<T> d4;
     T g;
-    kl_value<T>(kappa[i], variant, kb, &g);
+    kl_eval<T>(k4.v[0], variant, kb, &g); d4.v[0] = go.v[0] * gscale * g;
+    kl_eval<T>(k4.v[1], variant, kb, &g); d4.v[1] = go.v[1] * gscale * g;
+    kl_eval<T>(k4.v[2], variant, kb, &g); d4.v[2] = go.v[2] * gscale * g;
+    kl_eval<T>(k4.v[3], variant, kb, &g); d4.v[3] = go.v[3] * gscale * g;
+    *reinterpret_cast<Vec4<T>*>(dkappa + 4 * i) = d4;
+  }
+  for (int64_t i = 4 * nvec + tid; i < n; i += stride) {
+    T g;
+    kl_eval<T>(kappa[i], variant, kb, &g);
     dkappa[i] = gout[i * gstride] * gscale * g;
   }
 }
+
+static inline bool ew_aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" int vmf_kl_fwd(const void* kappa, void* out, double* sum_out, double* workspace, double alpha,
                           int64_t n, int variant, int dtype, vmf_stream_t stream) {
@@ -150,11 +182,16 @@ extern "C" int vmf_kl_fwd(const void* kappa, void* out, double* sum_out, double*
   VMF_REQUIRE(dtype == VMF_F32 || dtype == VMF_F64, VMF_ERR_DTYPE, "dtype %d", dtype);
   VMF_REQUIRE(n == 0 || kappa, VMF_ERR_BAD_ARG, "vmf_kl_fwd: null kappa");
   KlBessel kb = make_kl_bessel();
-  int grid = vmf_grid_for(n, 256, VMF_KL_WORKSPACE_DOUBLES);
+  int grid = vmf_grid_for(dtype == VMF_F32 ? (n + 3) / 4 : n, 256, VMF_KL_WORKSPACE_DOUBLES);
   if (n > 0) {
-    VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(kl_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                                 (const T*)kappa, (T*)out, sum_out ? workspace : nullptr, n,
-                                                 variant, kb));
+    if (dtype == VMF_F32 && ew_aligned16(kappa) && ew_aligned16(out)) {
+      hipLaunchKernelGGL((kl_fwd_kernel<float, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                         (const float*)kappa, (float*)out, sum_out ? workspace : nullptr, n, variant, kb);
+    } else {
+      VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((kl_fwd_kernel<T, 1>), dim3(grid), dim3(256), 0,
+                                                   (hipStream_t)stream, (const T*)kappa, (T*)out,
+                                                   sum_out ? workspace : nullptr, n, variant, kb));
+    }
     int rc = vmf_check_launch("vmf_kl_fwd");
     if (rc) return rc;
   }
@@ -175,9 +212,15 @@ extern "C" int vmf_kl_bwd(const void* kappa, const void* gout, int64_t gout_stri
   VMF_REQUIRE(kappa && gout && dkappa, VMF_ERR_BAD_ARG, "vmf_kl_bwd: null pointer");
   KlBessel kb = make_kl_bessel();
   int grid = vmf_grid_for(n, 256);
-  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(kl_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                               (const T*)kappa, (const T*)gout, gout_stride, (T)gscale,
-                                               (T*)dkappa, n, variant, kb));
+  if (dtype == VMF_F32 && ew_aligned16(kappa) && ew_aligned16(dkappa) && (gout_stride == 0 || ew_aligned16(gout))) {
+    hipLaunchKernelGGL((kl_bwd_kernel<float, 4>), dim3(vmf_grid_for((n + 3) / 4, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)kappa, (const float*)gout, gout_stride, (float)gscale,
+                       (float*)dkappa, n, variant, kb);
+  } else {
+    VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((kl_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0,
+                                                 (hipStream_t)stream, (const T*)kappa, (const T*)gout, gout_stride,
+                                                 (T)gscale, (T*)dkappa, n, variant, kb));
+  }
   return vmf_check_launch("vmf_kl_bwd");
 }
 

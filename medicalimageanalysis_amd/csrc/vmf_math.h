@@ -158,6 +158,196 @@ VMF_HD T kl_value(T kappa, int variant, const KlBessel& kb, T* grad) {
   return kl;
 }
 
+// ---- fp32 fast path of the KL variants ------------------------------------------------------------------------
+// The accurate version above spends ~500 instructions per element in libm's sinh / cosh / log / exp (and, for the
+// S^1 form, two double Chebyshev sums); the streams over kappa then run at a few percent of the memory rate.  For
+// fp32 tensors the contract is 1e-4 relative, which the hardware exp2 / log2 and single-precision series meet with
+// two orders of magnitude to spare.  The stable m = 2 form keeps the double path (k A - k cancels for large k).
+VMF_HD float fast_exp2(float x) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __builtin_amdgcn_exp2f(x);
+#else
+  return ::exp2f(x);
+#endif
+}
+VMF_HD float fast_log2(float x) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __builtin_amdgcn_logf(x);
+#else
+  return ::log2f(x);
+#endif
+}
+// e^x: the product x * log2(e) is split so that its rounding error (up to 1e-5 relative at |x| ~ 88) is fed back
+VMF_HD float fast_exp(float x) {
+  const float L2E = 1.44269504088896341f, L2E_LO = 1.925963033500097e-8f;  // log2(e) = L2E + L2E_LO in fp32 pairs
+  const float t = x * L2E;
+  // beyond the exponent range the result is 0 or inf whatever r is (and an infinite t would make r NaN)
+  const float r = ::fabsf(t) < 256.0f ? ::fmaf(x, L2E, -t) + x * L2E_LO : 0.0f;
+  return fast_exp2(t) * (1.0f + 0.69314718056f * r);
+}
+// a / b through the hardware reciprocal (1 ulp) instead of the IEEE division sequence (~10 instructions)
+VMF_HD float fast_rcp(float x) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __builtin_amdgcn_rcpf(x);
+#else
+  // the hardware reciprocal has no denormal results: mimic that so host-side checks see what the device computes
+  const float r = 1.0f / x;
+  return ::fabsf(r) < 1.17549435e-38f ? ::copysignf(0.0f, r) : r;
+#endif
+}
+VMF_HD float fast_log(float x) { return 0.69314718055994530942f * fast_log2(x); }
+
+// sinh and cosh of k >= 0 with sinhf's overflow point (k > 89.416): Taylor below 1 (no cancellation), the two
+// exponentials up to 10, exp(k - ln 2) beyond (sinh = cosh to 2e-9 there)
+VMF_HD void fast_sinh_cosh(float k, float* sh, float* ch) {
+  if (k > 10.0f) {
+    *sh = *ch = fast_exp(k - 0.69314718055994530942f);
+    return;
+  }
+  const float e = fast_exp(k), ei = fast_rcp(e);
+  *ch = 0.5f * (e + ei);
+  if (k < 1.0f) {
+    const float k2 = k * k;
+    *sh = k * (1.0f + k2 * (1.0f / 6.0f + k2 * (1.0f / 120.0f + k2 * (1.0f / 5040.0f + k2 * (1.0f / 362880.0f)))));
+  } else {
+    *sh = 0.5f * (e - ei);
+  }
+}
+
+VMF_HD float cheb_sum_f32(const float* c, int n, float t) {
+  float b0 = 0.0f, b1 = 0.0f;
+  const float t2 = 2.0f * t;
+  for (int k = n - 1; k >= 1; --k) {
+    const float b = ::fmaf(t2, b0, c[k]) - b1;
+    b1 = b0;
+    b0 = b;
+  }
+  return ::fmaf(t, b0, c[0]) - b1;
+}
+// log k - log(sinh k + eps) + k cosh k / (sinh k + eps) - 1 and its derivative for k > 0 (eps >= 0): the common
+// form of model/spherical_vae.py:161-169, model/torus_vae.py:190-194, CNN_experiment/circular_VAE.py:126-129.
+// Below 1 everything is expressed through the small quantities p = sinh k / k - 1, c1 = cosh k - 1 and
+// q = (sinh k + eps) / k - 1, so nothing cancels (the textbook order loses all digits of the O(k^2) result to
+// log k - log sinh k and 1/k - k / sinh^2 k).  The derivative uses cosh^2 - sinh^2 = 1:
+// d/dk = 1/k + k (eps sinh k - 1) / (sinh k + eps)^2.
+VMF_HD void kl_m3_eps_fast(float k, float eps, float* kl, float* g) {
+  if (k < 1.0f) {
+    const float k2 = k * k;
+    const float p = k2 * (1.0f / 6.0f + k2 * (1.0f / 120.0f + k2 * (1.0f / 5040.0f + k2 * (1.0f / 362880.0f))));
+    const float c1 = k2 * (0.5f + k2 * (1.0f / 24.0f + k2 * (1.0f / 720.0f + k2 * (1.0f / 40320.0f))));
+    const float rk = fast_rcp(k);
+    const float q = p + eps * rk;
+    const float l1p = q < 0.01f ? q * (1.0f - q * (0.5f - q * (1.0f / 3.0f))) : fast_log(1.0f + q);
+    const float opq = 1.0f + q;
+    const float ropq = fast_rcp(opq);
+    *kl = (c1 - q) * ropq - l1p;
+    const float sh = k * (1.0f + p);
+    *g = q * (2.0f + q) * (ropq * ropq * rk) + eps * sh * ropq * ropq * rk;
+    return;
+  }
+  float sh, C;
+  fast_sinh_cosh(k, &sh, &C);
+  const float S = sh + eps;
+  const float rS = fast_rcp(S);  // flushes to 0 once S > 2^126; every use below tolerates that
+  // cosh / (sinh + eps): beyond 10 the two are one number E, and E / (E + eps) = 1 - eps / (E + eps) stays exact
+  // when 1 / (E + eps) underflows; an overflowed E gives the reference's inf / inf
+  const float ratio = k > 10.0f ? (sh > 3.4028234e38f ? NAN : 1.0f - eps * rS) : C * rS;
+  *kl = fast_log(k) - fast_log(S) + k * ratio - 1.0f;
+  *g = fast_rcp(k) + k * (eps * sh - 1.0f) * (rS * rS);
+}
+
+// Same values and NaN / inf behaviour as kl_value<float> (to the tolerance above); returns false when there is no
+// fast form (the stable m = 2 variant; non-positive or NaN kappa in the unguarded variants, which are the accurate
+// form's business).
+VMF_HD bool kl_value_fast(float kappa, int variant, float* kl_out, float* grad) {
+  float kl = 0.0f, g = 0.0f;
+  switch (variant) {
+    case VMF_KL_SPHERICAL_PIECEWISE: {
+      const float eps = 1e-8f;
+      if (kappa != kappa) return false;
+      const float k = kappa < eps ? eps : kappa;
+      const float pass = (kappa >= eps) ? 1.0f : 0.0f;
+      if (k < 1e-3f) {
+        kl = 0.0f; g = 0.0f;
+      } else if (k > 20.0f) {
+        const float e2 = fast_exp(-2.0f * k);
+        const float coth = 1.0f + 2.0f * e2;
+        kl = fast_log(k) - (k - 0.69314718055994530942f) + k * coth - 1.0f;
+        g = pass * (fast_rcp(k) - 1.0f + coth - 4.0f * k * e2);
+      } else {
+        kl_m3_eps_fast(k, eps, &kl, &g);
+        g *= pass;
+      }
+    } break;
+    case VMF_KL_TORUS_RAW: {
+      if (!(kappa > 0.0f)) return false;
+      kl_m3_eps_fast(kappa, 0.0f, &kl, &g);
+    } break;
+    case VMF_KL_CIRCULAR_EPS: {
+      if (!(kappa > 0.0f)) return false;
+      kl_m3_eps_fast(kappa, 1e-6f, &kl, &g);
+    } break;
+    case VMF_KL_S1_I0I1: {
+      // regular_cnn/s1_vae.py:83-88 with unscaled I0, I1: NaN once e^|k| overflows, as there.  1 - I1/I0 comes
+      // from its own series on both intervals (for large k the two scaled functions agree to 1/(2k)), which
+      // keeps the derivative k (1 - A)(1 + A) - A accurate where k - A - k A^2 would cancel.
+      if (kappa != kappa) return false;
+      const float a = ::fabsf(kappa);
+      float e0, A, omA;
+      if (a <= 8.0f) {
+        const float t = 0.25f * a - 1.0f;
+        e0 = cheb_sum_f32(I0E_A_F32, I0E_A_F32_N, t);
+        omA = cheb_sum_f32(I01R_A_F32, I01R_A_F32_N, t);
+        A = 1.0f - omA;
+      } else {
+        const float ra = fast_rcp(a);
+        const float t = 16.0f * ra - 1.0f;
+        const float B0 = cheb_sum_f32(I0E_B_F32, I0E_B_F32_N, t);
+        e0 = B0 * ::sqrtf(ra);
+        omA = cheb_sum_f32(I01D_B_F32, I01D_B_F32_N, t) * ra * fast_rcp(B0);
+        A = 1.0f - omA;
+      }
+      const float i0 = e0 * fast_exp(a);
+      if (i0 > 3.4028234e38f) A = omA = NAN;  // inf / inf in the reference
+      kl = a * A - fast_log(i0);
+      g = a * omA * (1.0f + A) - A;
+      if (kappa < 0.0f) g = -g;
+    } break;
+    case VMF_KL_STABLE_M3: {
+      const float k = kappa;
+      if (k < 1.0f) {
+        if (!(k > 0.0f)) return false;
+        kl_m3_eps_fast(k, 0.0f, &kl, &g);  // the cancellation-free small-k form
+      } else {
+        const float e2 = fast_exp(-2.0f * k);
+        const float om = 1.0f - e2;
+        const float rom = fast_rcp(om);
+        const float coth = (1.0f + e2) * rom;
+        const float log_sinh = k + fast_log(om) - 0.69314718055994530942f;
+        kl = fast_log(k) - log_sinh + k * coth - 1.0f;
+        g = fast_rcp(k) - k * (4.0f * e2 * rom * rom);
+      }
+    } break;
+    default:
+      return false;
+  }
+  *kl_out = kl;
+  *grad = g;
+  return true;
+}
+
+// value + derivative for the kernels: the fast form for fp32 where there is one, the accurate form otherwise
+template <typename T>
+VMF_HD T kl_eval(T kappa, int variant, const KlBessel& kb, T* grad) {
+  return kl_value<T>(kappa, variant, kb, grad);
+}
+template <>
+VMF_HD float kl_eval<float>(float kappa, int variant, const KlBessel& kb, float* grad) {
+  float kl;
+  if (kl_value_fast(kappa, variant, &kl, grad)) return kl;
+  return kl_value<float>(kappa, variant, kb, grad);
+}
+
 // ---- general-m pieces ---------------------------------------------------------------------------
 template <typename T>
 VMF_HD void wood_consts(T kappa, int m, T* a, T* b, T* d) {

@@ -61,6 +61,12 @@ void hc_kl_f64(const double* k, double* out, double* dout, int64_t n, int varian
   KlBessel kb = make_kl_bessel();
   for (int64_t i = 0; i < n; ++i) out[i] = kl_value<double>(k[i], variant, kb, &dout[i]);
 }
+// returns 0 when the variant has no fast form
+int hc_kl_fast_f32(const float* k, float* out, float* dout, int64_t n, int variant) {
+  int ok = 1;
+  for (int64_t i = 0; i < n; ++i) ok &= (int)kl_value_fast(k[i], variant, &out[i], &dout[i]);
+  return ok;
+}
 void hc_kl_f32(const float* k, float* out, float* dout, int64_t n, int variant) {
   KlBessel kb = make_kl_bessel();
   for (int64_t i = 0; i < n; ++i) out[i] = kl_value<float>(k[i], variant, kb, &dout[i]);

@@ -293,6 +293,36 @@ def test_kl_gradients(golden, oracle):
     assert torch.isfinite(klmod.kl_per_sample(big, "stable_m2")).all()
 
 
+@pytest.mark.parametrize("name", ["spherical", "torus", "circular", "s1", "stable_m3"])
+def test_kl_fp32_fast_path_dense_grid(oracle, name):
+    """fp32 tensors take the hardware-transcendental form of the KL terms: value and derivative on a dense grid
+    against the oracle evaluated in double, and the reference's NaN behaviour past the overflow point"""
+    variant = klmod.VARIANTS[name]
+    kk = np.exp(np.linspace(np.log(2e-3), np.log(88.0), 6001)).astype(np.float32)
+    r64, g64, _ = oracle.vmf_kl(kk.astype(np.float64), variant)
+    t = T(kk).requires_grad_()
+    out = klmod.kl_per_sample(t, name)
+    np.testing.assert_allclose(N(out), r64, rtol=2e-5, atol=3e-6)
+    out.sum().backward()
+    err = np.abs(N(t.grad).astype(np.float64) - g64)
+    tol = 1e-4 * np.abs(g64) + 2e-7 / np.minimum(kk.astype(np.float64), 1.0) + 1e-6
+    assert (err <= tol).all(), (kk[err > tol][:5], N(t.grad)[err > tol][:5], g64[err > tol][:5])
+    big = T(np.array([89.5, 100.0, 1e3, 1e4], dtype=np.float32))
+    v = N(klmod.kl_per_sample(big, name))
+    if name in ("torus", "circular", "s1"):
+        assert np.isnan(v).all()          # sinh / I0 overflow: inf / inf in the reference
+    else:
+        r, _, _ = oracle.vmf_kl(N(big).astype(np.float64), variant)
+        np.testing.assert_allclose(v, r, rtol=2e-5)
+    # unaligned views and lengths that are not multiples of four use the scalar tail / scalar kernel
+    base = T(kk)
+    for lo, hi in ((1, 1 + 1023), (0, 5), (3, 4)):
+        np.testing.assert_allclose(N(klmod.kl_per_sample(base[lo:hi], name)), r64[lo:hi], rtol=2e-5, atol=3e-6)
+        s = float(klmod.kl_sum(base[lo:hi], name))
+        # per-element rounding of O(1) intermediates (log I0 near 1) is ~6e-8 and need not average out
+        assert abs(s - r64[lo:hi].sum()) <= 2e-5 * abs(r64[lo:hi].sum()) + 1e-7 * (hi - lo) + 1e-6
+
+
 def test_kl_large_reduction_matches_oracle(oracle):
     gen = np.random.default_rng(3)
     k = np.exp(gen.uniform(0, np.log(100.0), 1 << 20)).astype(np.float32)

@@ -102,6 +102,48 @@ def test_device_kl_matches_reference(hc, golden, oracle, tag, name, variant):
     np.testing.assert_allclose(dout[fin], o_d[fin], rtol=1e-6 if tag == "f64" else 2e-3, atol=1e-6)
 
 
+def _close_grad(got, want, k, rtol):
+    err = np.abs(got.astype(np.float64) - want)
+    tol = rtol * np.abs(want) + 2e-7 / np.minimum(k.astype(np.float64), 1.0) + 1e-6
+    bad = err > tol
+    assert not bad.any(), (k[bad][:5], got[bad][:5], want[bad][:5])
+
+
+@pytest.mark.parametrize("name,variant", [("spherical", 0), ("torus", 1), ("circular", 2), ("s1", 3)])
+def test_device_fast_fp32_kl_matches_reference(hc, golden, oracle, name, variant):
+    """the fp32 fast form of the KL terms (hardware exp2 / log2 on the device, exp2f / log2f here; single-precision
+    Chebyshev i0e / i1e) against the reference's fp32 values and the oracle's double derivative"""
+    g = golden("g_kl")
+    k = np.ascontiguousarray(g["kappa_f32"])
+    ref = g[f"{name}_f32"]
+    out, dout = np.empty_like(k), np.empty_like(k)
+    assert hc.hc_kl_fast_f32(_p(k), _p(out), _p(dout), C.c_int64(k.size), variant) == 1
+    keep = ~((k > 88.72) & (k < 89.42))
+    np.testing.assert_array_equal(np.isnan(out)[keep], np.isnan(ref)[keep])
+    np.testing.assert_array_equal(np.isinf(out)[keep], np.isinf(ref)[keep])
+    fin = np.isfinite(ref) & keep
+    np.testing.assert_allclose(out[fin], ref[fin], rtol=1e-4, atol=2e-4)
+    _, o_d, _ = oracle.vmf_kl(k.astype(np.float64), variant)  # the derivative in double: the fp32 textbook form cancels
+    fin = np.isfinite(o_d) & np.isfinite(dout) & keep
+    # 1/k + k (sh S - C^2)/S^2 cancels ~1/k against ~-1/k: fp32 leaves |error| ~ 6e-8 / k whatever the math library
+    _close_grad(dout[fin], o_d[fin], k[fin], rtol=2e-3)
+    # a dense grid against the oracle in double: the error stays far inside the 1e-4 contract
+    kk = np.exp(np.linspace(np.log(2e-3), np.log(85.0), 4001)).astype(np.float32)
+    o2, d2 = np.empty_like(kk), np.empty_like(kk)
+    hc.hc_kl_fast_f32(_p(kk), _p(o2), _p(d2), C.c_int64(kk.size), variant)
+    r64, g64, _ = oracle.vmf_kl(kk.astype(np.float64), variant)
+    np.testing.assert_allclose(o2, r64, rtol=2e-5, atol=3e-6)
+    _close_grad(d2, g64, kk, rtol=1e-4)
+
+
+def test_fast_kl_has_no_form_for_stable_m2(hc):
+    k = np.ones(4, np.float32)
+    out, dout = np.empty_like(k), np.empty_like(k)
+    assert hc.hc_kl_fast_f32(_p(k), _p(out), _p(dout), C.c_int64(4), 5) == 0
+    assert hc.hc_kl_fast_f32(_p(k), _p(out), _p(dout), C.c_int64(4), 4) == 1
+    np.testing.assert_allclose(out, np.log(1.0) - np.log(np.sinh(1.0)) + 1 / np.tanh(1.0) - 1.0, rtol=1e-6)
+
+
 def test_device_rsample_rows_match_reference(hc, golden):
     g = golden("g_rsample")
     p = "ew_f64_s0_"
