@@ -27,6 +27,10 @@
 #endif
 constexpr int TILE_ROWS = VMF_TILE_ROWS;
 constexpr int WAVES = VMF_WAVES;
+// Consecutive tiles per wave: 1 for every shape.  Narrow rows make small tiles (128 rows x 20 B for m = 2), but
+// walking 4-8 tiles per wave measured 10-20 % SLOWER there (m = 2: 0.217 -> 0.258 ms, m = 10: 0.464 -> 0.508 ms for
+// 2^24 rows): more waves in flight beat fewer wave launches.
+constexpr int tiles_per_wave(int) { return 1; }
 constexpr uint32_t SLOT_GAUSS = 0x10000u;
 constexpr int BWD_STEPS = 16;
 
@@ -139,13 +143,21 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
   const int sub = lane % LPR, grp = lane / LPR;
   const int m = FAST ? 4 * LPR * P : p.m;
   const bool pre = !FAST && p.prop_e != nullptr;
+  // Circle (m = 2) with counter noise: a proposal needs two uniforms (the Beta(1/2,1/2) angle and the accept draw)
+  // and the tangent "direction" is one sign, so one Philox call serves two proposals (words x,y then z,w of call
+  // k >> 1) and bit 0 of the first call's word x (below the 23 bits u01 uses) is the sign.  The sign travels to
+  // phase 2 in the sign bit of the parked 1 - w (which is never negative).
+  const bool circle = LPR == 1 && !FAST && m == 2 && !pre && p.gauss == nullptr;
   T* const sw = s_w[wave];
   T* const somw = s_omw[wave];
 
-  {
-    const int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+  constexpr int TPW = tiles_per_wave(LPR);
+#pragma unroll 1
+  for (int tw = 0; tw < TPW; ++tw) {
+    const int64_t tile = ((int64_t)blockIdx.x * WAVES + wave) * TPW + tw;
     const int64_t tile0 = tile * TILE_ROWS;  // wave-uniform
     const int64_t left = p.n - tile0;
+    if (TPW > 1 && left <= 0) break;
     const int ntile = left <= 0 ? 0 : (left < TILE_ROWS ? (int)left : TILE_ROWS);
     const T* const kap_t = p.kappa + tile0 * p.kappa_stride;
     const uint64_t grow0 = p.row0 + (uint64_t)tile0;
@@ -161,6 +173,8 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
       int my = lane, next = 64, k = 0;
       bool active = my < ntile;
       T a = 0, b = 0, d = 0;
+      U4 rc = {0u, 0u, 0u, 0u};  // circle: the current call's four words
+      bool neg = false;           // circle: the row's sign bit
       if (active) {
         if (pre) wood_consts<T>(kap_t[my * p.kappa_stride], m, &a, &b, &d);
         else b = somw[my];
@@ -172,6 +186,13 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
           if (pre) {
             const int64_t row = tile0 + my;
             acc = wood_try<T>(a, b, d, m, p.prop_e[row * p.max_prop + k], p.prop_u[row * p.max_prop + k], &w, &omw);
+          } else if (LPR == 1 && circle) {
+            if ((k & 1) == 0) {
+              rc = philox4x32_10(grow0 + (uint64_t)my, (uint32_t)(k >> 1), key);
+              if (k == 0) neg = (rc.x & 1u) != 0u;
+            }
+            acc = wood_try_counter<T>(b, 2, (T)0.5, u01<T>((k & 1) ? rc.z : rc.x), u01<T>((k & 1) ? rc.w : rc.y),
+                                      &w, &omw);
           } else {
             const U4 r = philox4x32_10(grow0 + (uint64_t)my, (uint32_t)k, key);
             acc = wood_try_counter<T>(b, m, u01<T>(r.x), u01<T>(r.y), u01<T>(r.z), &w, &omw);
@@ -179,7 +200,7 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
           if (k + 1 >= p.max_prop) acc = true;  // the last proposal allowed is taken regardless
           if (acc) {
             sw[my] = w;
-            somw[my] = omw;
+            somw[my] = (LPR == 1 && circle && neg) ? -omw : omw;
             if (p.w_out) p.w_out[tile0 + my] = w;
             if (p.omw_out) p.omw_out[tile0 + my] = omw;
             if (p.accept_idx) p.accept_idx[tile0 + my] = k;
@@ -252,7 +273,12 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
           if (j == 0 && sub == 0) g[0][0] = (T)0;
         } else {
           load4<T, VEC>(mrow, 4 * chunk, m, mu[j]);
-          noise4<T, VEC>(ga_t ? ga_t + (int64_t)rr * m : nullptr, grow0 + (uint64_t)rr, chunk, m, key, g[j]);
+          if (LPR == 1 && circle) {
+            g[j][0] = g[j][2] = g[j][3] = (T)0;
+            g[j][1] = __builtin_signbit(somw[rr]) ? (T)-1 : (T)1;
+          } else {
+            noise4<T, VEC>(ga_t ? ga_t + (int64_t)rr * m : nullptr, grow0 + (uint64_t)rr, chunk, m, key, g[j]);
+          }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -267,7 +293,7 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
       dd = group_allreduce_sum<LPR, T>(dd);
       gm = group_allreduce_sum<LPR, T>(gm);
       const T mu0 = LPR == 1 ? mu[0][0] : __shfl(mu[0][0], lane - sub, 64);
-      const T w = sw[rr], omw = somw[rr];
+      const T w = sw[rr], omw = (LPR == 1 && circle) ? M<T>::abs(somw[rr]) : somw[rr];
       T c2 = omw * ((T)1 + w);
       c2 = c2 < (T)1e-10 ? (T)1e-10 : c2;
       const T f = F<T>::sqrt(c2) * F<T>::rsqrt(gg);
@@ -342,7 +368,13 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
       const int chunk = j * LPR + sub;
       load4<T, VEC>(mrow, 4 * chunk, m, mu[j]);
       load4<T, VEC>(grow_, 4 * chunk, m, G[j]);
-      noise4<T, VEC>(p.gauss ? p.gauss + row * (int64_t)m : nullptr, p.row0 + (uint64_t)row, chunk, m, key, g[j]);
+      if (LPR == 1 && m == 2 && p.gauss == nullptr) {  // circle: the tangent is the sign bit of the row's first call
+        const U4 r0 = philox4x32_10(p.row0 + (uint64_t)row, 0u, key);
+        g[j][0] = g[j][2] = g[j][3] = (T)0;
+        g[j][1] = (r0.x & 1u) ? (T)-1 : (T)1;
+      } else {
+        noise4<T, VEC>(p.gauss ? p.gauss + row * (int64_t)m : nullptr, p.row0 + (uint64_t)row, chunk, m, key, g[j]);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bool first = (chunk == 0 && i == 0);
@@ -470,8 +502,9 @@ static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   const int passes = (chunks + lpr - 1) / lpr;
   const bool full = vec && (passes == 1 || passes == 2 || passes == 4 || passes == 8) && m == 4 * lpr * passes;
   const int64_t n_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
-  int64_t gb = (n_tiles + WAVES - 1) / WAVES;
-  // One tile per wave, every tile its own wave: workgroups are dispatched in index order, so the waves in flight at
+  const int tpw = tiles_per_wave(lpr);
+  int64_t gb = (n_tiles + (int64_t)WAVES * tpw - 1) / ((int64_t)WAVES * tpw);
+  // One tile per wave (several for narrow rows, see tiles_per_wave), every tile its own wave: workgroups are dispatched in index order, so the waves in flight at
   // any moment work on neighbouring tiles (DRAM-page and TLB locality).  A persistent grid of 2048 workgroups walking
   // strided tiles measured 13 % slower on the same kernel body.
   VMF_REQUIRE(gb <= 0x7fffffff, VMF_ERR_UNSUPPORTED, "n=%lld rows need more than 2^31 workgroups", (long long)n);

@@ -409,7 +409,7 @@ def test_general_rsample_predrawn_accept_index_bit_exact(oracle, tag, m, n):
 
 
 @pytest.mark.parametrize("tag", ["f64", "f32"])
-@pytest.mark.parametrize("m,n", [(64, 70000), (512, 3000), (10, 4097), (3, 999)])
+@pytest.mark.parametrize("m,n", [(64, 70000), (512, 3000), (10, 4097), (3, 999), (2, 50001), (4, 3000)])
 def test_general_rsample_philox_vs_oracle(oracle, tag, m, n):
     gen = np.random.default_rng(200 + m)
     dt = np.float64 if tag == "f64" else np.float32
@@ -594,6 +594,48 @@ def test_spherical_vae_train_step_batch128():
     assert any(not torch.equal(a, b) for a, b in zip(before, model.parameters()))
     assert all(torch.isfinite(p).all() for p in model.parameters())
     os.environ.pop("VMF_RNG")
+
+
+def test_circle_counter_noise_backward_regenerates_the_forward_sign():
+    """m = 2 with in-kernel noise: two proposals per Philox call and a one-bit tangent.  The backward pass
+    regenerates that bit; check it against autograd through the forward restated in torch with the accepted proposal
+    (recovered from w) and the sign (recovered from z) held fixed."""
+    gen = torch.Generator(device=DEV).manual_seed(8)
+    n = 4000
+    mu = torch.nn.functional.normalize(torch.randn(n, 2, device=DEV, dtype=torch.float64, generator=gen), dim=-1)
+    mu = (mu * 0.99).requires_grad_()
+    kappa = torch.exp(torch.rand(n, device=DEV, dtype=torch.float64, generator=gen) * np.log(1e3)).requires_grad_()
+    q = VonMisesFisher(mu, kappa, validate_args=False, generator=rng.PhiloxGenerator(4, 3))
+    z = q.rsample()
+    c = torch.randn(n, 2, device=DEV, dtype=torch.float64, generator=gen)
+    (z * c).sum().backward()
+    mud, kd = mu.detach(), kappa.detach()
+    e1 = torch.tensor([1.0, 0.0], device=DEV, dtype=torch.float64)
+
+    def compose(m_, k_, e, sgn):
+        cc = torch.sqrt(4 * k_ * k_ + 1)
+        b = 1 / (2 * k_ + cc)
+        den = 1 - (1 - b) * e
+        ww = (1 - (1 + b) * e) / den
+        om = 2 * b * e / den
+        f = torch.sqrt(torch.clamp(om * (1 + ww), min=1e-10))
+        zp = torch.stack([ww, sgn * f], dim=-1)
+        d = e1 - m_
+        return zp - 2 * (zp * d).sum(-1, keepdim=True) / (d * d).sum(-1, keepdim=True) * d
+
+    # w from z: undo the Householder reflection (an involution)
+    d = e1 - mud
+    zp = z.detach() - 2 * (z.detach() * d).sum(-1, keepdim=True) / (d * d).sum(-1, keepdim=True) * d
+    w, sgn = zp[:, 0], torch.sign(zp[:, 1])
+    b = 1 / (2 * kd + torch.sqrt(4 * kd * kd + 1))
+    e = (1 - w) / ((1 + b) - w * (1 - b))
+    assert (sgn < 0).float().mean().item() == pytest.approx(0.5, abs=0.05)     # both signs occur
+    mu2, k2 = mud.clone().requires_grad_(), kd.clone().requires_grad_()
+    zt = compose(mu2, k2, e, sgn)
+    np.testing.assert_allclose(N(zt), N(z), rtol=0, atol=1e-9)
+    (zt * c).sum().backward()
+    np.testing.assert_allclose(N(mu.grad), N(mu2.grad), rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(N(kappa.grad), N(k2.grad), rtol=1e-6, atol=1e-9)
 
 
 @pytest.mark.parametrize("m", [3, 10, 64, 512])
