@@ -136,12 +136,25 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in evs]))
+    kern_all = [s.elapsed_time(e) for s, e in evs]
+    kern_ms = float(np.mean(kern_all))
 
     # sanity: the output is a set of unit vectors (cheap, outside the timed region)
     nrm = z[:: max(1, n // 4096)].norm(dim=-1)
     assert torch.isfinite(nrm).all() and float((nrm - 1).abs().max()) < 1e-3, "rsample produced non-unit rows"
 
+    copy_gbps = None
+    if rank == 0:
+        # context for the roofline fraction: what a plain device copy of the same 2 x n x m x 4 bytes reaches on this
+        # GPU (outside the timed region; the output buffer is scratch by now)
+        cev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        z.copy_(mu)
+        for s_, e_ in cev:
+            s_.record(stream)
+            z.copy_(mu)
+            e_.record(stream)
+        torch.cuda.synchronize(dev)
+        copy_gbps = 2 * mu.numel() * 4 / (min(s_.elapsed_time(e_) for s_, e_ in cev) * 1e-3) / 1e9
     if rank == 0:
         bytes_per_row = (2 * m + 1 + (1 if a.log_prob else 0)) * 4
         achieved = n * bytes_per_row / (kern_ms * 1e-3) / 1e9
@@ -172,7 +185,9 @@ def main():
                        "rows_per_gpu": n, "m": m, "sharding": "rows, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "bytes_per_row": bytes_per_row},
+                         "kernel_ms": kern_ms, "kernel_ms_min": float(np.min(kern_all)),
+                         "kernel_ms_median": float(np.median(kern_all)), "bytes_per_row": bytes_per_row,
+                         "device_copy_GBps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps},
         }
         if world == 1 and a.cpu_rows > 0:
             out["cpu_baseline"] = cpu_baseline(m, a.cpu_rows, seed)

@@ -79,7 +79,9 @@ int vmf3_rsample_fwd(const void* loc, const void* scale, const void* u, const vo
 
 /* Backward of the above (what autograd derives from sampler/von_mises_fisher.py:30, 58-84):
  * dloc (n_loc rows of 3) and dscale (n_scale) receive J^T grad_z.  They are overwritten.  When several
- * output rows share a loc row or a scale element the partial results are combined with float atomics. */
+ * output rows share a loc row or a scale element the partial results are combined with float atomics --
+ * unless n_loc == n_scale == number of output rows: then row o of dloc / dscale receives output row o's
+ * contribution and the caller reduces over the rows that share an operand (reproducible run to run). */
 int vmf3_rsample_bwd(const void* loc, const void* scale, const void* u, const void* eps, const void* grad_z,
                      void* dloc, void* dscale, int64_t n_loc, int64_t n_scale, int ndim, const int64_t* odims,
                      const int64_t* w_str, const int64_t* k_str, const int64_t* l_str, const int64_t* e_str,

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void vmf3_bwd_kernel(const T* __restrict__ loc
                                                        const T* __restrict__ u, const T* __restrict__ eps,
                                                        const T* __restrict__ gz, T* __restrict__ dloc,
                                                        T* __restrict__ dscale, Bcast bc, int64_t n_out,
-                                                       PhiloxArg ka) {
+                                                       int per_row, PhiloxArg ka) {
   const PhiloxKey key = philox_resolve(ka);
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += stride) {
@@ -149,7 +149,10 @@ __global__ __launch_bounds__(256) void vmf3_bwd_kernel(const T* __restrict__ loc
     T g[3] = {gz[3 * o], gz[3 * o + 1], gz[3 * o + 2]};
     T dr[3], dk;
     v3_backward_row<T>(r, k, uu, e, g, dr, &dk);
-    if (bc.identity) {
+    if (per_row) {  // one gradient row per output row; the caller sums the rows that share an operand
+      dloc[3 * o] = dr[0]; dloc[3 * o + 1] = dr[1]; dloc[3 * o + 2] = dr[2];
+      dscale[o] = dk;
+    } else if (bc.identity) {
       dloc[3 * li] = dr[0]; dloc[3 * li + 1] = dr[1]; dloc[3 * li + 2] = dr[2];
       dscale[ki] = dk;
     } else {
@@ -196,7 +199,11 @@ extern "C" int vmf3_rsample_bwd(const void* loc, const void* scale, const void* 
   size_t es = dtype == VMF_F32 ? 4 : 8;
   // identity also requires that the outputs are exactly as large as the result
   if (bc.identity && !(n_loc == n_out && n_scale == n_out)) bc.identity = 0;
-  if (!bc.identity) {
+  // Outputs as large as the result although operands are shared: per-row mode.  Row o of dloc / dscale receives the
+  // contribution of output row o and the caller adds up the rows that share a loc row / scale element in an order
+  // of its choosing -- the run-to-run reproducible alternative to the float atomics below.
+  const int per_row = !bc.identity && n_loc == n_out && n_scale == n_out;
+  if (!bc.identity && !per_row) {
     if (hipMemsetAsync(dloc, 0, es * 3 * (size_t)n_loc, (hipStream_t)stream) != hipSuccess ||
         hipMemsetAsync(dscale, 0, es * (size_t)n_scale, (hipStream_t)stream) != hipSuccess)
       return vmf_check_launch("vmf3_rsample_bwd memset");
@@ -206,7 +213,8 @@ extern "C" int vmf3_rsample_bwd(const void* loc, const void* scale, const void* 
   int grid = vmf_grid_for(n_out, 256);
   VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(vmf3_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                                (const T*)loc, (const T*)scale, (const T*)u, (const T*)eps,
-                                               (const T*)grad_z, (T*)dloc, (T*)dscale, bc, n_out, key));
+                                               (const T*)grad_z, (T*)dloc, (T*)dscale, bc, n_out, per_row,
+                                               key));
   return vmf_check_launch("vmf3_rsample_bwd");
 }
 

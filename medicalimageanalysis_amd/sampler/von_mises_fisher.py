@@ -7,6 +7,8 @@ checks and autograd glue.
 """
 import math  # noqa: F401  (re-exported: the reference's model files reach `math` through `from sampler.von_mises_fisher import *`)
 
+import os
+
 import torch
 from torch.distributions import Distribution, constraints
 from torch.distributions.kl import register_kl
@@ -98,17 +100,33 @@ class _VMF3RSample(torch.autograd.Function):
         plan = ctx.plan
         dev = locc.device
         gzc = gz.to(locc.dtype).contiguous()
-        dloc, dscale = torch.empty_like(locc), torch.empty_like(scalec)
+        odims, n_out = plan["odims"], _numel(plan["odims"])
+        n_loc, n_scale = locc.numel() // 3, scalec.numel()
+        shared = not (n_loc == n_out and n_scale == n_out)
+        # Rows that share a loc row / scale element (the (B, 1) scale of the VAEs, sample shapes): by default the kernel
+        # writes one gradient row per output row and torch sums them (same bits every run); VMF_ATOMIC_BWD=1 lets the
+        # kernel combine them with float atomics instead (no temporary, order varies run to run).
+        per_row = shared and n_out > 0 and os.environ.get("VMF_ATOMIC_BWD", "0") != "1"
+        if per_row:
+            dloc = torch.empty(tuple(odims) + (3,), device=dev, dtype=locc.dtype)
+            dscale = torch.empty(tuple(odims), device=dev, dtype=locc.dtype)
+        else:
+            dloc, dscale = torch.empty_like(locc), torch.empty_like(scalec)
         if dloc.numel() or dscale.numel():
             with torch.cuda.device(dev):
                 rc = _lib.lib().vmf3_rsample_bwd(
                     _lib.ptr(locc), _lib.ptr(scalec), _lib.ptr(uc), _lib.ptr(epsc), _lib.ptr(gzc), _lib.ptr(dloc),
-                    _lib.ptr(dscale), locc.numel() // 3, scalec.numel(), len(plan["odims"]),
-                    _lib.i64_array(plan["odims"]), _lib.i64_array(plan["w_str"]), _lib.i64_array(plan["k_str"]),
+                    _lib.ptr(dscale), n_out if per_row else n_loc, n_out if per_row else n_scale, len(odims),
+                    _lib.i64_array(odims), _lib.i64_array(plan["w_str"]), _lib.i64_array(plan["k_str"]),
                     _lib.i64_array(plan["l_str"]), _lib.i64_array(plan["e_str"]), _lib.dtype_code(locc), ctx.seed,
                     ctx.offset, _lib.ptr(ctx.offset_dev), _lib.stream_ptr(dev))
             _lib.check(rc, "vmf3_rsample_bwd")
-        return dloc.view(ctx.loc_shape), dscale.view(ctx.scale_shape), None, None, None, None, None, None
+        if per_row:
+            ldims = [d for d, (n, st) in enumerate(zip(odims, plan["l_str"])) if st == 0 and n > 1]
+            kdims = [d for d, (n, st) in enumerate(zip(odims, plan["k_str"])) if st == 0 and n > 1]
+            dloc = dloc.sum(dim=ldims) if ldims else dloc
+            dscale = dscale.sum(dim=kdims) if kdims else dscale
+        return dloc.reshape(ctx.loc_shape), dscale.reshape(ctx.scale_shape), None, None, None, None, None, None
 
 
 class VonMisesFisher3D(Distribution):

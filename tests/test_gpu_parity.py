@@ -331,6 +331,65 @@ def test_kl_large_reduction_matches_oracle(oracle):
     assert abs(got - s) <= 2e-5 * abs(s)
 
 
+def test_vmf3_broadcast_backward_is_reproducible_and_matches_atomics(monkeypatch):
+    """(B, 1) scale -> (B, B, 3): per-row gradients summed by torch give the same bits on every run; the atomic
+    variant agrees to rounding; a sample shape with an elementwise scale reduces over the right dimension"""
+    gen = torch.Generator(device=DEV).manual_seed(12)
+    B = 96
+    loc = torch.randn(B, 3, device=DEV, generator=gen).requires_grad_()
+    kap = (torch.rand(B, 1, device=DEV, generator=gen) * 50 + 1).requires_grad_()
+    u = torch.rand(B, 1, device=DEV, generator=gen)
+    eps = torch.randn(B, 3, device=DEV, generator=gen)
+    c = torch.randn(B, B, 3, device=DEV, generator=gen)
+
+    def grads():
+        loc.grad = kap.grad = None
+        z = VonMisesFisher3D(loc, kap, validate_args=False).rsample_with_noise(u, eps)
+        assert z.shape == (B, B, 3)
+        (z * c).sum().backward()
+        return loc.grad.clone(), kap.grad.clone()
+
+    a1, b1 = grads()
+    a2, b2 = grads()
+    assert torch.equal(a1, a2) and torch.equal(b1, b2)
+    monkeypatch.setenv("VMF_ATOMIC_BWD", "1")
+    a3, b3 = grads()
+    np.testing.assert_allclose(N(a3), N(a1), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(N(b3), N(b1), rtol=2e-4, atol=2e-5)
+    monkeypatch.delenv("VMF_ATOMIC_BWD")
+    # against torch autograd of the reference's formulas (fp64)
+    loc64 = loc.detach().double().requires_grad_()
+    kap64 = kap.detach().double().requires_grad_()
+    l = loc64 / (loc64.norm(dim=-1, keepdim=True) + 1e-5)
+    k = kap64
+    ud, ed = u.double(), eps.double()
+    w = 1 + torch.logsumexp(torch.stack([ud.log(), (1 - ud).log() - 2 * k], 0), 0) / k
+    v = ed - (ed * l).sum(-1, keepdim=True) * l
+    v = v / (v.norm(dim=-1, keepdim=True) + 1e-8)
+    we = w.unsqueeze(-1)
+    z = we * l + torch.sqrt(torch.clamp(1 - we ** 2, 1e-10, 1.0)) * v
+    (z * c.double()).sum().backward()
+    np.testing.assert_allclose(N(a1), N(loc64.grad), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(N(b1), N(kap64.grad), rtol=2e-3, atol=2e-4)
+    # sample shape (5,) with an elementwise scale (B,): loc and scale gradients sum over the sample dimension
+    k1 = (torch.rand(B, device=DEV, generator=gen, dtype=torch.float64) * 50 + 1).requires_grad_()
+    l1 = torch.randn(B, 3, device=DEV, generator=gen, dtype=torch.float64).requires_grad_()
+    u5 = torch.rand(5, B, device=DEV, generator=gen, dtype=torch.float64)
+    e5 = torch.randn(5, B, 3, device=DEV, generator=gen, dtype=torch.float64)
+    c5 = torch.randn(5, B, 3, device=DEV, generator=gen, dtype=torch.float64)
+    z5 = VonMisesFisher3D(l1, k1, validate_args=False).rsample_with_noise(u5, e5, torch.Size([5]))
+    (z5 * c5).sum().backward()
+    ga, gb = l1.grad.clone(), k1.grad.clone()
+    l1.grad = k1.grad = None
+    tot = 0
+    for s_ in range(5):
+        zs = VonMisesFisher3D(l1, k1, validate_args=False).rsample_with_noise(u5[s_], e5[s_])
+        tot = tot + (zs * c5[s_]).sum()
+    tot.backward()
+    np.testing.assert_allclose(N(ga), N(l1.grad), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(N(gb), N(k1.grad), rtol=1e-10, atol=1e-12)
+
+
 # ---- uniform prior / S^1 -----------------------------------------------------------------------------------------
 def test_spherical_uniform(golden, monkeypatch):
     g = golden("g_uniform")
