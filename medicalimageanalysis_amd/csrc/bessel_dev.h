@@ -26,6 +26,7 @@ struct BesselOrder {
   int neg_frac;        // -1 < v < 0 (non integer)
   int unsupported;     // non-integer v <= -1
   int amos;            // apply AMOS's |z| <= 2^30 limit (scipy.special.ive); 0 for i0e / i1e
+  int half;            // closed form available: 1 -> v = 1/2, 2 -> v = -1/2, 3 -> v = 3/2; 0 otherwise
 };
 
 static inline BesselOrder make_bessel_order(double v, int amos) {
@@ -41,6 +42,7 @@ static inline BesselOrder make_bessel_order(double v, int amos) {
   o.odd = o.is_int && fmod(v, 2.0) != 0.0;
   o.lgam_v1 = (o.v > -1.0) ? lgamma(o.v + 1.0) : 0.0;
   o.lgam_av1 = lgamma(o.av + 1.0);
+  o.half = (o.v == 0.5) ? 1 : (o.v == -0.5) ? 2 : (o.v == 1.5) ? 3 : 0;
   return o;
 }
 
@@ -102,6 +104,20 @@ VMF_HD double i1e_pos(double x) {
   return cheb_sum(I1E_B, I1E_B_N, 16.0 / x - 1.0) / ::sqrt(x);
 }
 
+// Half-integer orders the reference's mean() and ive's backward use (sampler/von_mises_fisher.py:38-43 calls
+// ive(3/2, k) / ive(1/2, k); the derivative of ive(1/2, .) needs ive(-1/2, .)): elementary closed forms,
+//   ive(1/2, x) = sqrt(2/(pi x)) (1 - e^{-2x}) / 2,   ive(-1/2, x) = sqrt(2/(pi x)) (1 + e^{-2x}) / 2,
+//   ive(3/2, x) = sqrt(2/(pi x)) [(1 + e^{-2x}) / 2 - (1 - e^{-2x}) / (2x)]   (x >= 1; below, the two terms cancel
+//   and the power series, a handful of terms there, is used instead).
+VMF_HD double ive_half_closed(int half, double x) {
+  const double pref = ::sqrt(0.63661977236758134308 / x);  // sqrt(2 / (pi x))
+  const double em = -::expm1(-2.0 * x);                     // 1 - e^{-2x}
+  if (half == 1) return pref * 0.5 * em;
+  const double ep = 2.0 - em;                               // 1 + e^{-2x}
+  if (half == 2) return pref * 0.5 * ep;
+  return pref * (0.5 * ep - 0.5 * em / x);
+}
+
 VMF_HD double ive_eval(const BesselOrder& o, double z) {
   if (z != z) return z;
   if (o.unsupported) return NAN;
@@ -115,6 +131,7 @@ VMF_HD double ive_eval(const BesselOrder& o, double z) {
   if (o.amos && x > VMF_AMOS_LIMIT) return NAN;
   if (isinf(x)) return 0.0;
   if (o.is_int && v <= 1.0) return sign * (v == 0.0 ? i0e_pos(x) : i1e_pos(x));
+  if (o.half && (o.half != 3 || x >= 1.0)) return ive_half_closed(o.half, x);
   if (o.neg_frac && x > 20.0) {
     // I_v = I_{-v} + (2/pi) sin(-v pi) K_{-v}; the K term is < 2 e^{-2x} relative: below one ulp here
     return ::exp(log_ive_pos(o.av, o.lgam_av1, x));
