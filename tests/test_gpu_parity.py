@@ -524,6 +524,23 @@ def test_general_rsample_distribution_ks():
         assert p > 1e-3, (m, kappa, p)
 
 
+def test_general_rsample_two_sample_ks_against_cpu_sampler(oracle):
+    """freshly drawn device samples against freshly drawn samples of the CPU sampler (different seeds): the
+    two-sample KS test on w = <z, mu> and on a tangent coordinate must not reject"""
+    import scipy.stats as st
+    for m, kappa in ((64, 30.0), (3, 2.0), (2, 5.0), (10, 100.0), (512, 5000.0)):
+        n = 20000
+        mu = np.zeros((n, m), dtype=np.float32)
+        mu[:, m // 2] = 1.0
+        kap = np.full(n, kappa, dtype=np.float32)
+        z_cpu, _, _ = oracle.vmf_rsample_philox(mu, kap, seed=111, offset=0, row0=0, max_prop=64)
+        q = VonMisesFisher(T(mu), T(kap), validate_args=False, generator=rng.PhiloxGenerator(222, 0))
+        z_gpu = N(q.rsample())
+        for comp in (m // 2, 0):
+            p = st.ks_2samp(z_gpu[:, comp].astype(np.float64), z_cpu[:, comp].astype(np.float64)).pvalue
+            assert p > 1e-3, (m, kappa, comp, p)
+
+
 def test_general_rsample_full_size_properties():
     """the headline configuration at full size, m = 64 and 2^24 rows, through size-independent properties: unit norm,
     <z,mu> = w, E[w] = A_m(kappa), shard-invariance of the tail rows"""

@@ -168,6 +168,25 @@ def main():
         print(f"| same step as one HIP graph ({mode} noise) | {ms_g:.3f} | - | {1e3 / ms_g:.0f} steps/s |")
     os.environ["VMF_RNG"] = "torch"
 
+    # --- the 28x28 / batch-128 step with the latent on S^9 (m = 10; one sample per row, the general-m sampler)
+    from medicalimageanalysis_amd.model.hyperspherical_vae import HypersphericalVAE
+    cfg9 = dict(cfg, latent_dim=10)
+    torch.manual_seed(0)
+    model9 = HypersphericalVAE(cfg9)
+    opt9 = torch.optim.Adam(model9.parameters(), lr=1e-3, capturable=True)
+
+    def step9():
+        z, x_mu, params = model9(x)
+        loss = model9._elbo(x, x_mu, params)
+        opt9.zero_grad(set_to_none=True)
+        loss.backward()
+        opt9.step()
+    ms_9 = timeit(step9, reps=30, warm=5)
+    print(f"| HypersphericalVAE train step B=128, latent S^9 (z 128x10) | {ms_9:.3f} | - | {1e3 / ms_9:.0f} steps/s |")
+    g9 = GraphedTrainStep(model9, opt9, loss_fn, [x])
+    ms_9g = timeit(lambda: g9(x), reps=30, warm=5)
+    print(f"| same step as one HIP graph | {ms_9g:.3f} | - | {1e3 / ms_9g:.0f} steps/s |")
+
     # --- consumers: fused ELBO on the (128, 128, 784) decoder output, torus embedding, latent losses
     from medicalimageanalysis_amd import losses
     B, D = 128, 784
