@@ -220,8 +220,11 @@ VMF_HD double vmf_log_norm(const VmfDim& d, double k) {
   return d.v * ::log(k) - d.half_m_log2pi - (log_ive_pos(d.v, d.lg_v1, k) + k);
 }
 // the same in single precision (|error| ~ 1e-6 (1 + |log C_m|)); used when the output tensor is fp32
+VMF_HD float vmf_log_norm_f32v(float v, float lg_v1, float half_m_log2pi, float k) {
+  return v * ::logf(k) - half_m_log2pi - (log_ive_pos_f32(v, lg_v1, k) + k);
+}
 VMF_HD float vmf_log_norm_f32(const VmfDim& d, float k) {
-  return (float)d.v * ::logf(k) - (float)d.half_m_log2pi - (log_ive_pos_f32((float)d.v, (float)d.lg_v1, k) + k);
+  return vmf_log_norm_f32v((float)d.v, (float)d.lg_v1, (float)d.half_m_log2pi, k);
 }
 // A_m(k) = I_{m/2}(k) / I_{m/2-1}(k)
 VMF_HD double vmf_mean_resultant(const VmfDim& d, double k) {

@@ -105,6 +105,7 @@ struct FwdParams {
   int64_t n; uint64_t row0;
   int mu_stride, kappa_stride, m, max_prop;
   PhiloxArg ka;
+  float lc_v, lc_lg, lc_c0;  // fp32 fused log_prob: m/2 - 1, lgamma(m/2), (m/2) log 2 pi
 };
 
 // Prefetch of the next step's mu rows for the fp32 streaming kernel.  The load is issued from inline asm so that its
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
   const PhiloxKey key = philox_resolve(p.ka);  // scalar: seed + host offset (+ device-resident offset)
   __shared__ T s_w[WAVES][TILE_ROWS];
   __shared__ T s_omw[WAVES][TILE_ROWS];
+  __shared__ float s_lc[sizeof(T) == 4 ? WAVES : 1][sizeof(T) == 4 ? TILE_ROWS : 1];  // log C_m(kappa), fp32 log_prob
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int RPI = 64 / LPR;  // rows per wave step
   const int sub = lane % LPR, grp = lane / LPR;
@@ -150,6 +152,7 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
   const bool circle = LPR == 1 && !FAST && m == 2 && !pre && p.gauss == nullptr;
   T* const sw = s_w[wave];
   T* const somw = s_omw[wave];
+  float* const slc = s_lc[sizeof(T) == 4 ? wave : 0];
 
   constexpr int TPW = tiles_per_wave(LPR);
 #pragma unroll 1
@@ -164,6 +167,11 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
 
     // ---- phase 1: rejection sampler, one row per lane; accepted lanes retire their row and are refilled with
     //      the next unassigned row of the tile (ballot + prefix popcount) ----
+    // fp32 fused log_prob: log C_m(kappa) of the tile's rows, evaluated in single precision here (two rows per lane)
+    // so that phase 2 writes log p once; fp64 outputs get theirs from the double-precision pre-pass kernel instead
+    if (sizeof(T) == 4 && p.logp)
+      for (int i = lane; i < ntile; i += 64)
+        slc[i] = vmf_log_norm_f32v(p.lc_v, p.lc_lg, p.lc_c0, (float)kap_t[i * p.kappa_stride]);
     if (!pre) {
       // b(kappa) of every row of the tile, coalesced, parked in the slab that later receives 1 - w
       for (int i = lane; i < ntile; i += 64) somw[i] = wood_b<T>(kap_t[i * p.kappa_stride], m);
@@ -335,11 +343,15 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
         if (p.logp && sub == 0) {
           const T mm = dd - (T)1 + (T)2 * mu0;                // |mu|^2
           const T mz = w * mu0 + f * gm - coef * (mu0 - mm);  // <mu, z>
-          p.logp[tile0 + rr] += kap_t[rr * p.kappa_stride] * mz;  // log C_m(kappa) was stored by the pre-pass
+          const T kmz = kap_t[rr * p.kappa_stride] * mz;
+          if (sizeof(T) == 4) slc[rr] += (float)kmz;  // written out coalesced once the tile is done
+          else p.logp[tile0 + rr] += kmz;              // log C_m(kappa) was stored by the pre-pass
         }
       }
     }
     wave_lds_sync();
+    if (sizeof(T) == 4 && p.logp)
+      for (int i = lane; i < ntile; i += 64) p.logp[tile0 + i] = (T)slc[i];
   }
 }
 
@@ -509,7 +521,11 @@ static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   // strided tiles measured 13 % slower on the same kernel body.
   VMF_REQUIRE(gb <= 0x7fffffff, VMF_ERR_UNSUPPORTED, "n=%lld rows need more than 2^31 workgroups", (long long)n);
   const int grid = (int)(gb < 1 ? 1 : gb);
-  if (logp_out)
+  {
+    const VmfDim dim = make_vmf_dim(m);
+    p.lc_v = (float)dim.v; p.lc_lg = (float)dim.lg_v1; p.lc_c0 = (float)dim.half_m_log2pi;
+  }
+  if (logp_out && sizeof(T) == 8)
     hipLaunchKernelGGL(vmf_log_norm_kernel<T>, dim3(vmf_grid_for(n, 256)), dim3(256), 0, s, (const T*)kappa,
                        kappa_stride, (T*)logp_out, n, make_vmf_dim(m));
   if (full && !prop_e) launch_fwd<T, 2>(p, grid, s);
