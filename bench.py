@@ -1,18 +1,20 @@
 #!/usr/bin/env python3
 """Benchmark of the vMF latent-sampling hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (the configuration the headline metric is quoted on): vMF rsample, m = 64, fp32,
+Workload (the configuration the headline metric is quoted on): batch vMF rsample + log_prob, m = 64, fp32,
 2^24 rows PER GPU, one (mu_i, kappa_i) per row, mu = normalize(randn), kappa = exp(U[0, ln 1e4]), noise from the
 in-kernel Philox streams keyed by the GLOBAL row index (rank r owns rows [r 2^24, (r+1) 2^24)): weak scaling, no
 data-path collective.  A step is one pass of `vmf_rsample_fwd` (C ABI of libvmf_hip.so) over the rank's rows with
-all inputs resident in HBM.  Rank 0 prints one JSON line.
+all inputs resident in HBM; it writes the sample z and, fused in the same kernel, log p(z).  `--no-log-prob` times
+the sampler alone.  Rank 0 prints one JSON line.
 
-roofline : algorithmic bytes per row (2m+1)*4 = 516 B (read mu, read kappa, write z) x rows per launch / the
-           kernel's average duration measured with HIP events on the launch stream, against 8000 GB/s.
+roofline : algorithmic bytes per row (2m+2)*4 = 520 B (read mu, read kappa, write z, write log p; 516 B without
+           log_prob) x rows per launch / the kernel's average duration measured with HIP events on the launch
+           stream, against 8000 GB/s.
 cpu_baseline : the CPU oracle (oracle/libvmf_oracle.so, same counters, OpenMP over rows) timed on the host cores
            of rank 0 on a bounded sample of the same workload.
 """
@@ -37,11 +39,15 @@ HBM_PEAK_GBPS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # the GPU needs ~10 launches of this size to settle its clocks (per-dispatch times in profiles/: 2.2, 2.0, 1.9 ...
+    # then 1.67-1.72 ms), hence the default warm-up
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows", type=int, default=1 << 24, help="rows per GPU")
     ap.add_argument("--m", type=int, default=64)
-    ap.add_argument("--log-prob", action="store_true", help="also write the fused log p(z) (520 B/row)")
+    ap.add_argument("--log-prob", dest="log_prob", action="store_true", default=True,
+                    help="write the fused log p(z) as well (520 B/row; the default)")
+    ap.add_argument("--no-log-prob", dest="log_prob", action="store_false", help="sampler alone (516 B/row)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-rows", type=int, default=1 << 22, help="rows of the CPU-baseline sample (0: skip)")
@@ -50,7 +56,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(m, rows, seed):
+def cpu_baseline(m, rows, seed, log_prob):
     """the oracle on the same workload, bounded sample, host cores of this rank"""
     from oracle import vmf_oracle as orc
 
@@ -62,14 +68,17 @@ def cpu_baseline(m, rows, seed):
     t0 = time.perf_counter()
     passes = 0
     while True:  # about 10 s of CPU work: repeated passes over the bounded sample, a new noise offset each pass
-        orc.vmf_rsample_philox(mu, kappa, seed=seed, offset=passes, row0=0, max_prop=64)
+        z, _, _ = orc.vmf_rsample_philox(mu, kappa, seed=seed, offset=passes, row0=0, max_prop=64)
+        if log_prob:
+            orc.vmf_log_prob(mu, kappa, z)
         passes += 1
         dt = time.perf_counter() - t0
         if dt >= 10.0 or passes >= 200:
             break
     return {"value": rows * passes / dt, "unit": "samples/s", "cores": int(orc.lib().orc_num_threads()),
             "kind": "port",
-            "sample": f"{passes} passes over {rows} rows of the same workload (m={m}, fp32, oracle's Philox), {dt:.1f} s"}
+            "sample": f"{passes} passes over {rows} rows of the same workload (m={m}, fp32, oracle's Philox"
+                      + (", + log_prob" if log_prob else "") + f"), {dt:.1f} s"}
 
 
 def main():
@@ -162,12 +171,13 @@ def main():
         try:
             with open(a.traffic_json) as f:
                 tj = json.load(f)
-            if tj.get("rows") == n and tj.get("m") == m:
+            if tj.get("rows") == n and tj.get("m") == m and bool(tj.get("log_prob", False)) == bool(a.log_prob):
                 traffic = tj.get("hbm_bytes_per_launch")
         except (OSError, ValueError):
             pass
         out = {
-            "metric": "vMF rsample samples/sec (m=64, batch 2^24)",
+            "metric": "vMF rsample samples/sec (m=64, batch 2^24)" if (m == 64 and n == 1 << 24) else
+                      f"vMF rsample samples/sec (m={m}, batch {n})",
             "value": world * n * a.steps / elapsed,
             "unit": "samples/s",
             "n_gpus": world,
@@ -179,9 +189,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"vMF rsample m={m}, {n} rows per GPU, one (mu,kappa) per row, kappa log-uniform "
-                                   f"[1,1e4], in-kernel Philox keyed by global row"
-                                   + (", fused log_prob" if a.log_prob else ""),
+            "config": {"workload": f"batch vMF rsample{' + log_prob (fused)' if a.log_prob else ''}, m={m}, {n} rows per "
+                                   f"GPU, one (mu,kappa) per row, kappa log-uniform [1,1e4], in-kernel Philox keyed "
+                                   f"by global row",
+                       "log_prob": bool(a.log_prob),
                        "rows_per_gpu": n, "m": m, "sharding": "rows, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
@@ -190,7 +201,7 @@ def main():
                          "device_copy_GBps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps},
         }
         if world == 1 and a.cpu_rows > 0:
-            out["cpu_baseline"] = cpu_baseline(m, a.cpu_rows, seed)
+            out["cpu_baseline"] = cpu_baseline(m, a.cpu_rows, seed, a.log_prob)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

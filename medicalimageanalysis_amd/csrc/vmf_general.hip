@@ -139,7 +139,9 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
   const PhiloxKey key = philox_resolve(p.ka);  // scalar: seed + host offset (+ device-resident offset)
   __shared__ T s_w[WAVES][TILE_ROWS];
   __shared__ T s_omw[WAVES][TILE_ROWS];
-  __shared__ float s_lc[sizeof(T) == 4 ? WAVES : 1][sizeof(T) == 4 ? TILE_ROWS : 1];  // log C_m(kappa), fp32 log_prob
+  // fp32 fused log_prob: log C_m(kappa) and kappa of the tile's rows (kappa is read from HBM once per row)
+  __shared__ float s_lc[sizeof(T) == 4 ? WAVES : 1][sizeof(T) == 4 ? TILE_ROWS : 1];
+  __shared__ float s_kp[sizeof(T) == 4 ? WAVES : 1][sizeof(T) == 4 ? TILE_ROWS : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int RPI = 64 / LPR;  // rows per wave step
   const int sub = lane % LPR, grp = lane / LPR;
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
   T* const sw = s_w[wave];
   T* const somw = s_omw[wave];
   float* const slc = s_lc[sizeof(T) == 4 ? wave : 0];
+  float* const skp = s_kp[sizeof(T) == 4 ? wave : 0];
 
   constexpr int TPW = tiles_per_wave(LPR);
 #pragma unroll 1
@@ -169,12 +172,17 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
     //      the next unassigned row of the tile (ballot + prefix popcount) ----
     // fp32 fused log_prob: log C_m(kappa) of the tile's rows, evaluated in single precision here (two rows per lane)
     // so that phase 2 writes log p once; fp64 outputs get theirs from the double-precision pre-pass kernel instead
-    if (sizeof(T) == 4 && p.logp)
-      for (int i = lane; i < ntile; i += 64)
-        slc[i] = vmf_log_norm_f32v(p.lc_v, p.lc_lg, p.lc_c0, (float)kap_t[i * p.kappa_stride]);
-    if (!pre) {
-      // b(kappa) of every row of the tile, coalesced, parked in the slab that later receives 1 - w
-      for (int i = lane; i < ntile; i += 64) somw[i] = wood_b<T>(kap_t[i * p.kappa_stride], m);
+    const bool lp32 = sizeof(T) == 4 && p.logp != nullptr;
+    if (lp32 || !pre) {
+      for (int i = lane; i < ntile; i += 64) {
+        const T kap = kap_t[i * p.kappa_stride];
+        if (lp32) {
+          skp[i] = (float)kap;
+          slc[i] = vmf_log_norm_f32v(p.lc_v, p.lc_lg, p.lc_c0, (float)kap);
+        }
+        // b(kappa) of every row of the tile, coalesced, parked in the slab that later receives 1 - w
+        if (!pre) somw[i] = wood_b<T>(kap, m);
+      }
       wave_lds_sync();
     }
     {
@@ -343,9 +351,8 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
         if (p.logp && sub == 0) {
           const T mm = dd - (T)1 + (T)2 * mu0;                // |mu|^2
           const T mz = w * mu0 + f * gm - coef * (mu0 - mm);  // <mu, z>
-          const T kmz = kap_t[rr * p.kappa_stride] * mz;
-          if (sizeof(T) == 4) slc[rr] += (float)kmz;  // written out coalesced once the tile is done
-          else p.logp[tile0 + rr] += kmz;              // log C_m(kappa) was stored by the pre-pass
+          if (sizeof(T) == 4) slc[rr] += skp[rr] * (float)mz;  // written out coalesced once the tile is done
+          else p.logp[tile0 + rr] += kap_t[rr * p.kappa_stride] * mz;  // log C_m(kappa) came from the pre-pass
         }
       }
     }

@@ -30,7 +30,7 @@ def stats(src, dst):
     print("wrote", dst)
 
 
-def pmc(dirs, rows, m, out_json, out_csv, kernel="vmf_rsample_fwd"):
+def pmc(dirs, rows, m, out_json, out_csv, log_prob=True, kernel="vmf_rsample_fwd"):
     agg = collections.defaultdict(list)
     for d in dirs:
         for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
@@ -43,12 +43,12 @@ def pmc(dirs, rows, m, out_json, out_csv, kernel="vmf_rsample_fwd"):
         w.writerow(["counter", "dispatches", "mean_per_dispatch"])
         for k in sorted(mean):
             w.writerow([k, len(agg[k]), mean[k]])
-    res = {"rows": rows, "m": m, "kernel": kernel}
+    res = {"rows": rows, "m": m, "log_prob": bool(log_prob), "kernel": kernel}
     if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
         fetch_b = mean["FETCH_SIZE"] * 1024 * 2  # gfx950: doubled
         write_b = mean["WRITE_SIZE"] * 1024
         res.update({"fetch_bytes_corrected": fetch_b, "write_bytes": write_b, "hbm_bytes_per_launch": fetch_b + write_b,
-                    "algorithmic_bytes_per_launch": rows * (2 * m + 1) * 4})
+                    "algorithmic_bytes_per_launch": rows * (2 * m + 1 + (1 if log_prob else 0)) * 4})
     with open(out_json, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res))
@@ -65,5 +65,7 @@ if __name__ == "__main__":
         ap.add_argument("--m", type=int, default=64)
         ap.add_argument("--out", default="profiles/traffic_latest.json")
         ap.add_argument("--csv", default="profiles/pmc_latest.csv")
+        ap.add_argument("--no-log-prob", dest="log_prob", action="store_false", default=True,
+                        help="the passes ran bench.py --no-log-prob (516 B/row instead of 520)")
         a = ap.parse_args()
-        pmc(a.dirs, a.rows, a.m, a.out, a.csv)
+        pmc(a.dirs, a.rows, a.m, a.out, a.csv, a.log_prob)
