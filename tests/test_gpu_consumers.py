@@ -334,3 +334,20 @@ def test_two_rank_sharded_sampling_on_the_device(tmp_path):
     outs = [p.communicate(timeout=100)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o
+
+
+def test_c_abi_driver_without_python_runs_the_headline_kernel():
+    """medicalimageanalysis_amd/abi_bench (tools/abi_bench.hip) links only libvmf_hip.so and the HIP runtime: the
+    same entry points from plain C++ with hipMalloc'ed buffers"""
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(_lib.library_path()), "abi_bench")
+    if not os.path.exists(exe):
+        pytest.skip("abi_bench not built")
+    run = subprocess.run([exe, str(1 << 20), "64", "5", "2"], capture_output=True, text=True, timeout=100)
+    assert run.returncode == 0, run.stdout + run.stderr
+    out = json.loads(run.stdout.strip().splitlines()[-1])
+    assert out["self_check"] == "ok" and out["rows"] == 1 << 20 and out["kernel_ms_min"] > 0
+    run = subprocess.run([exe, "1000", "10", "2", "1"], capture_output=True, text=True, timeout=100)   # scalar-access shape
+    assert run.returncode == 0, run.stdout + run.stderr
