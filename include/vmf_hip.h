@@ -87,6 +87,16 @@ int vmf3_rsample_bwd(const void* loc, const void* scale, const void* u, const vo
                      const int64_t* w_str, const int64_t* k_str, const int64_t* l_str, const int64_t* e_str,
                      int dtype, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream);
 
+/* _sample_w3 alone  sampler/von_mises_fisher.py:50-64: w[i] = 1 + logsumexp([log u_i, log(1-u_i) - 2k]) / k with
+ * k = scale[i mod n_scale] (u, w have shape sample_shape + scale.shape, n elements); u null: Philox(index i, slot 0),
+ * the same stream vmf3_rsample_fwd uses for its u.  bwd writes grad_w[i] * dw/dk per ELEMENT (n values); the caller
+ * sums over the sample dimensions. */
+int vmf3_sample_w_fwd(const void* scale, const void* u, void* w, int64_t n, int64_t n_scale, int dtype, uint64_t seed,
+                      uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream);
+int vmf3_sample_w_bwd(const void* scale, const void* u, const void* grad_w, void* dscale_rows, int64_t n,
+                      int64_t n_scale, int dtype, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                      vmf_stream_t stream);
+
 /* CNN_experiment/von_mises_fisher.py:88-108 with the reference's sign: logp = k<l,x> - lognorm,
  * lognorm = log k - log 4pi - log(sinh k + 1e-10).  logp / lognorm nullable. */
 int vmf3_log_prob_ref(const void* loc, const void* scale, const void* x, void* logp, void* lognorm, int64_t n,

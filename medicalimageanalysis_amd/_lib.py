@@ -26,6 +26,8 @@ _PROTOS = {
     "vmf3_rsample_fwd": [_P, _P, _P, _P, _P, _P, _I, _I64P, _I64P, _I64P, _I64P, _I64P, _I, _U64, _U64, _P, _P],
     "vmf3_rsample_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I64P, _I64P, _I64P, _I64P, _I64P, _I, _U64,
                          _U64, _P, _P],
+    "vmf3_sample_w_fwd": [_P, _P, _P, _I64, _I64, _I, _U64, _U64, _P, _P],
+    "vmf3_sample_w_bwd": [_P, _P, _P, _P, _I64, _I64, _I, _U64, _U64, _P, _P],
     "vmf3_log_prob_ref": [_P, _P, _P, _P, _P, _I64, _I, _P],
     "vmf3_log_prob_ref_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _P],
     "vmf3_mean": [_P, _P, _P, _I64, _I, _P],

@@ -218,6 +218,58 @@ extern "C" int vmf3_rsample_bwd(const void* loc, const void* scale, const void* 
   return vmf_check_launch("vmf3_rsample_bwd");
 }
 
+// ---- _sample_w3 alone (sampler/von_mises_fisher.py:50-64): w = 1 + logsumexp([log u, log(1-u) - 2k]) / k ----------
+// u has shape sample_shape + scale.shape, so element i pairs with scale[i mod n_scale].
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void vmf3_w_kernel(const T* __restrict__ scale, const T* __restrict__ u,
+                                                     const T* __restrict__ gw, T* __restrict__ out, int64_t n,
+                                                     int64_t n_scale, PhiloxArg ka) {
+  const PhiloxKey key = philox_resolve(ka);
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const T k = scale[i % n_scale];
+    const T uu = v3_draw_u<T>(u, i, key);
+    T L, x2;
+    const T w = v3_w<T>(uu, k, &L, &x2);
+    if (!BWD) {
+      out[i] = w;
+    } else {  // d w / d k = -L / k^2 - 2 sigma / k, sigma = exp(x2 - L): per-element term, the caller sums over samples
+      const T sig = M<T>::exp(x2 - L);
+      out[i] = gw[i] * (-L / (k * k) - (T)2 * sig / k);
+    }
+  }
+}
+
+extern "C" int vmf3_sample_w_fwd(const void* scale, const void* u, void* w, int64_t n, int64_t n_scale, int dtype,
+                                 uint64_t seed, uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0 && n_scale >= 0, VMF_ERR_BAD_ARG, "vmf3_sample_w_fwd: negative size");
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(n_scale > 0 && n % n_scale == 0, VMF_ERR_BAD_ARG, "vmf3_sample_w_fwd: n %lld does not tile n_scale %lld",
+              (long long)n, (long long)n_scale);
+  VMF_REQUIRE(scale && w, VMF_ERR_BAD_ARG, "vmf3_sample_w_fwd: null pointer");
+  PhiloxArg key = make_philox_arg(seed, offset, offset_dev);
+  int grid = vmf_grid_for(n, 256);
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((vmf3_w_kernel<T, false>), dim3(grid), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)scale, (const T*)u, (const T*)nullptr,
+                                               (T*)w, n, n_scale, key));
+  return vmf_check_launch("vmf3_sample_w_fwd");
+}
+
+extern "C" int vmf3_sample_w_bwd(const void* scale, const void* u, const void* grad_w, void* dscale_rows, int64_t n,
+                                 int64_t n_scale, int dtype, uint64_t seed, uint64_t offset,
+                                 const uint64_t* offset_dev, vmf_stream_t stream) {
+  VMF_REQUIRE(n >= 0 && n_scale >= 0, VMF_ERR_BAD_ARG, "vmf3_sample_w_bwd: negative size");
+  if (n == 0) return VMF_OK;
+  VMF_REQUIRE(n_scale > 0 && n % n_scale == 0, VMF_ERR_BAD_ARG, "vmf3_sample_w_bwd: n does not tile n_scale");
+  VMF_REQUIRE(scale && grad_w && dscale_rows, VMF_ERR_BAD_ARG, "vmf3_sample_w_bwd: null pointer");
+  PhiloxArg key = make_philox_arg(seed, offset, offset_dev);
+  int grid = vmf_grid_for(n, 256);
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((vmf3_w_kernel<T, true>), dim3(grid), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)scale, (const T*)u, (const T*)grad_w,
+                                               (T*)dscale_rows, n, n_scale, key));
+  return vmf_check_launch("vmf3_sample_w_bwd");
+}
+
 // ---- log_prob (reference sign) and mean ----------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void vmf3_log_prob_ref_kernel(const T* __restrict__ loc,

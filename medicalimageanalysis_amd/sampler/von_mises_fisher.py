@@ -129,6 +129,39 @@ class _VMF3RSample(torch.autograd.Function):
         return dloc.reshape(ctx.loc_shape), dscale.reshape(ctx.scale_shape), None, None, None, None, None, None
 
 
+class _VMF3SampleW(torch.autograd.Function):
+    """w = 1 + logsumexp([log u, log(1-u) - 2k]) / k elementwise over sample_shape + scale.shape, gradient to scale"""
+
+    @staticmethod
+    def forward(ctx, scale, u, w_shape, seed, offset, offset_dev=None):
+        dev = _lib.require_hip(scale, u)
+        sc = scale.detach().contiguous()
+        uc = None if u is None else u.to(sc.dtype).contiguous()
+        w = torch.empty(w_shape, device=dev, dtype=sc.dtype)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().vmf3_sample_w_fwd(_lib.ptr(sc), _lib.ptr(uc), _lib.ptr(w), w.numel(), sc.numel(),
+                                              _lib.dtype_code(sc), seed, offset, _lib.ptr(offset_dev),
+                                              _lib.stream_ptr(dev))
+        _lib.check(rc, "vmf3_sample_w_fwd")
+        ctx.save_for_backward(sc, uc)
+        ctx.meta = (seed, offset, offset_dev, tuple(scale.shape))
+        return w
+
+    @staticmethod
+    def backward(ctx, gw):
+        sc, uc = ctx.saved_tensors
+        seed, offset, offset_dev, sshape = ctx.meta
+        dev = sc.device
+        g = gw.to(sc.dtype).contiguous()
+        rows = torch.empty_like(g)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().vmf3_sample_w_bwd(_lib.ptr(sc), _lib.ptr(uc), _lib.ptr(g), _lib.ptr(rows), g.numel(),
+                                              sc.numel(), _lib.dtype_code(sc), seed, offset, _lib.ptr(offset_dev),
+                                              _lib.stream_ptr(dev))
+        _lib.check(rc, "vmf3_sample_w_bwd")
+        return rows.reshape((-1,) + sshape).sum(0), None, None, None, None, None
+
+
 class VonMisesFisher3D(Distribution):
     """
     Simpler von Mises-Fisher distribution on the unit sphere in R^3 (sampler/von_mises_fisher.py:7-86).
@@ -174,6 +207,19 @@ class VonMisesFisher3D(Distribution):
 
     def stddev(self):
         return self.scale  # (:46-48)
+
+    def _sample_w3(self, sample_shape):
+        """w of shape sample_shape + scale.shape by the exact inverse CDF of the m = 3 cosine marginal (:50-64);
+        one uniform draw (torch.rand, as the reference, or the in-kernel stream when VMF_RNG=philox)."""
+        shape = torch.Size(sample_shape) + self.scale.shape
+        _lib.require_hip(self.scale)
+        if rng.rng_mode() == "torch":
+            u = torch.rand(shape, device=self.device, dtype=self.dtype)  # :56
+            seed, offset, offset_dev = 0, 0, None
+        else:
+            u = None
+            seed, offset, offset_dev = rng.default_generator.ticket(self.scale.device)
+        return _VMF3SampleW.apply(self.scale, u, tuple(shape), seed, offset, offset_dev)
 
     def rsample(self, sample_shape=torch.Size()):
         """Reparameterised sample of shape broadcast(sample_shape + scale.shape, sample_shape + batch_shape) + (3,)

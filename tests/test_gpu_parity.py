@@ -331,6 +331,55 @@ def test_kl_large_reduction_matches_oracle(oracle):
     assert abs(got - s) <= 2e-5 * abs(s)
 
 
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_sample_w3_matches_reference(golden, tag, monkeypatch):
+    """VonMisesFisher3D._sample_w3 (sampler/von_mises_fisher.py:50-64): golden w for the golden u (torch.rand is the
+    only draw it makes), the gradient to scale, and the exact CDF in in-kernel-noise mode"""
+    g = golden("g_rsample")
+    monkeypatch.setenv("VMF_RNG", "torch")
+    for p, ss in ((f"ew_{tag}_s0_", ()), (f"ew_{tag}_s3_", ()), (f"outer_{tag}_s1_", ()), (f"ss5_{tag}_", (5,))):
+        loc, scale, u = T(g[p + "loc"]), T(g[p + "scale"]), T(g[p + "u"])
+        if p + "w" in g.files:
+            w_ref = g[p + "w"]                      # the reference's own w
+        else:                                       # shapes without a stored w: the reference's formula in double
+            ud, kd = u.double(), scale.double()
+            w_ref = N(1 + torch.logsumexp(torch.stack([ud.log(), (1 - ud).log() - 2 * kd], 0), 0) / kd)
+        q = VonMisesFisher3D(loc, scale, validate_args=False)
+        with mock.patch("torch.rand", return_value=u) as m:
+            w = q._sample_w3(torch.Size(ss))
+        assert m.call_args[0][0] == torch.Size(ss) + scale.shape
+        assert w.shape == w_ref.shape
+        if tag == "f64":
+            np.testing.assert_allclose(N(w), w_ref, rtol=0, atol=1e-12)
+        else:  # w = 1 + L / kappa amplifies the last bit of log() by 1 / kappa
+            k = np.broadcast_to(g[p + "scale"], w_ref.shape).astype(np.float64)
+            lu = np.abs(np.log(np.maximum(np.broadcast_to(g[p + "u"], w_ref.shape).astype(np.float64), 1e-300)))
+            tol = 2.0 ** -23 + 4 * 2.0 ** -24 * np.maximum(1.0, lu) / k
+            assert (np.abs(N(w).astype(np.float64) - w_ref) <= tol).all()
+    # gradient to scale against autograd of the reference's formula, sample shape (4,)
+    k = (torch.rand(33, 1, device=DEV, dtype=torch.float64) * 50 + 0.5).requires_grad_()
+    u = torch.rand(4, 33, 1, device=DEV, dtype=torch.float64)
+    c = torch.randn(4, 33, 1, device=DEV, dtype=torch.float64)
+    q = VonMisesFisher3D(torch.randn(33, 3, device=DEV, dtype=torch.float64), k, validate_args=False)
+    with mock.patch("torch.rand", return_value=u):
+        w = q._sample_w3(torch.Size([4]))
+    (w * c).sum().backward()
+    got = k.grad.clone()
+    k.grad = None
+    w2 = 1 + torch.logsumexp(torch.stack([u.log(), (1 - u).log() - 2 * k], 0), 0) / k
+    np.testing.assert_allclose(N(w), N(w2), rtol=0, atol=1e-13)
+    (w2 * c).sum().backward()
+    np.testing.assert_allclose(N(got), N(k.grad), rtol=1e-10, atol=1e-13)
+    # in-kernel noise: w follows F(w) = (e^{k w} - e^{-k}) / (e^{k} - e^{-k})
+    import scipy.stats as st
+    monkeypatch.setenv("VMF_RNG", "philox")
+    kap = 3.0
+    q = VonMisesFisher3D(torch.tensor([[0.0, 0.0, 1.0]], device=DEV), torch.tensor([kap], device=DEV), validate_args=False)
+    w = N(q._sample_w3(torch.Size([20000])).double()).ravel()
+    cdf = lambda x: (np.exp(kap * x) - np.exp(-kap)) / (np.exp(kap) - np.exp(-kap))  # noqa: E731
+    assert st.kstest(w, cdf).pvalue > 1e-3
+
+
 def test_vmf3_broadcast_backward_is_reproducible_and_matches_atomics(monkeypatch):
     """(B, 1) scale -> (B, B, 3): per-row gradients summed by torch give the same bits on every run; the atomic
     variant agrees to rounding; a sample shape with an elementwise scale reduces over the right dimension"""
