@@ -120,7 +120,7 @@ def main():
 
     def step(i):
         rc = lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(z), None, None, None, _lib.ptr(logp), n,
-                                 m, None, None, 0, None, 64, row0, seed, i, None, _lib.VMF_F32, sp)
+                                 m, None, None, 0, None, 64, row0, seed, i, None, 0, _lib.VMF_F32, sp)
         if rc:
             _lib.check(rc, "vmf_rsample_fwd")
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VMF_HIP_VERSION 110
+#define VMF_HIP_VERSION 120
 
 typedef void* vmf_stream_t; /* hipStream_t */
 
@@ -150,17 +150,21 @@ int vmf_kl_bwd(const void* kappa, const void* gout, int64_t gout_stride, double 
  * The accepted proposal index (first accepted, or the last one tried when none is) goes to accept_idx.
  * Outputs w_out (n), omw_out (n; 1 - w computed without cancellation, what the backward wants),
  * accept_idx (n, int32), logp_out (n; log p(z) fused) are nullable. */
+/* flags of vmf_rsample_fwd / vmf_rsample_bwd */
+#define VMF_FLAG_NORMALIZE_MU 1 /* mu rows are raw (e.g. straight from a GEMM): sample around mu / ||mu||; the
+                                  backward pass returns the gradient with respect to the RAW rows */
 int vmf_rsample_fwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, void* z, void* w_out,
                     void* omw_out, int32_t* accept_idx, void* logp_out, int64_t n, int m, const void* prop_e, const void* prop_u,
                     int n_prop, const void* gauss, int max_prop, uint64_t row0, uint64_t seed, uint64_t offset,
-                    const uint64_t* offset_dev, int dtype, vmf_stream_t stream);
+                    const uint64_t* offset_dev, int flags, int dtype, vmf_stream_t stream);
 /* Backward through z given the saved w and 1-w (omw; null: 1-w is recomputed from w) -- path-wise through
  * b(kappa), the accepted proposal held fixed.
  * gauss null: the Gaussians are regenerated from the same counters.  dmu is (n, m); with mu_stride == 0 or
  * kappa_stride == 0 the caller reduces dmu / dkappa over rows. */
 int vmf_rsample_bwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, const void* w,
                     const void* omw, const void* grad_z, const void* gauss, void* dmu, void* dkappa, int64_t n, int m, uint64_t row0,
-                    uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int dtype, vmf_stream_t stream);
+                    uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int flags, int dtype,
+                    vmf_stream_t stream);
 /* logp = k<mu,x> + log C_m(k),  log C_m = (m/2-1) log k - (m/2) log 2pi - (log ive(m/2-1,k) + k) */
 int vmf_log_prob_fwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, const void* x,
                      void* logp, int64_t n, int m, int dtype, vmf_stream_t stream);

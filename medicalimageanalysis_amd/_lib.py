@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _DEFAULT = os.path.join(_HERE, "libvmf_hip.so")
 
 VMF_F32, VMF_F64 = 0, 1
+FLAG_NORMALIZE_MU = 1
 KL_SPHERICAL_PIECEWISE, KL_TORUS_RAW, KL_CIRCULAR_EPS, KL_S1_I0I1, KL_STABLE_M3, KL_STABLE_M2 = range(6)
 KL_WORKSPACE_DOUBLES = 1024
 ELBO_WORKSPACE_DOUBLES = 2048
@@ -38,8 +39,8 @@ _PROTOS = {
     "vmf_kl_fwd": [_P, _P, _P, _P, _D, _I64, _I, _I, _P],
     "vmf_kl_bwd": [_P, _P, _I64, _D, _P, _I64, _I, _I, _P],
     "vmf_rsample_fwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _I, _P, _I, _U64, _U64, _U64, _P,
-                        _I, _P],
-    "vmf_rsample_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I, _U64, _U64, _U64, _P, _I, _P],
+                        _I, _I, _P],
+    "vmf_rsample_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I, _U64, _U64, _U64, _P, _I, _I, _P],
     "vmf_log_prob_fwd": [_P, _I64, _P, _I64, _P, _P, _I64, _I, _I, _P],
     "vmf_log_prob_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _I, _I, _P],
     "vmf_entropy_kl_fwd": [_P, _P, _P, _P, _I64, _I, _I, _P],

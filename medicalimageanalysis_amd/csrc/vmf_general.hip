@@ -41,6 +41,7 @@ struct GenParams {
   T* z; T* w_out; T* omw_out; int32_t* accept_idx; T* logp;
   const T* prop_e; const T* prop_u; const T* gauss;
   int64_t n; int m; int max_prop; uint64_t row0;
+  int normalize;  // mu rows are raw: use mu / ||mu|| (and chain the gradient through the normalisation)
   PhiloxArg ka; VmfDim dim;
   // backward only
   const T* w_in; const T* omw_in; const T* gz; T* dmu; T* dkappa;
@@ -104,6 +105,7 @@ struct FwdParams {
   const T* prop_e; const T* prop_u; const T* gauss;
   int64_t n; uint64_t row0;
   int mu_stride, kappa_stride, m, max_prop;
+  int normalize;  // mu rows are raw: the sample is drawn around mu / ||mu||
   PhiloxArg ka;
   float lc_v, lc_lg, lc_c0;  // fp32 fused log_prob: m/2 - 1, lgamma(m/2), (m/2) log 2 pi
 };
@@ -299,23 +301,30 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const bool first = (j == 0 && i == 0 && sub == 0);
-          const T dmu = first ? (T)1 - mu[j][i] : mu[j][i];
           gg += g[j][i] * g[j][i];
-          dd += dmu * dmu;
-          gm += g[j][i] * mu[j][i];  // g is zero at element 0
+          dd += first ? (T)0 : mu[j][i] * mu[j][i];  // |mu|^2 without its first element
+          gm += g[j][i] * mu[j][i];                   // g is zero at element 0
         }
       }
       gg = group_allreduce_sum<LPR, T>(gg);
       dd = group_allreduce_sum<LPR, T>(dd);
       gm = group_allreduce_sum<LPR, T>(gm);
-      const T mu0 = LPR == 1 ? mu[0][0] : __shfl(mu[0][0], lane - sub, 64);
+      T mu0 = LPR == 1 ? mu[0][0] : __shfl(mu[0][0], lane - sub, 64);
+      // raw mean directions: everything below is written for mu / ||mu||; `inv` carries the scale to the elements
+      // (the exact-fit streaming instantiation is kept free of this option: a run-time flag there costs 3 % of the
+      //  headline kernel; raw means take the guarded 128-bit instantiation instead, see the launch code)
+      const T inv = (!FAST && p.normalize) ? F<T>::rsqrt(dd + mu0 * mu0) : (T)1;
+      mu0 *= inv;
+      gm *= inv;
+      const T d0 = (T)1 - mu0;
+      dd = d0 * d0 + dd * (inv * inv);  // |e1 - mu|^2
       const T w = sw[rr], omw = (LPR == 1 && circle) ? M<T>::abs(somw[rr]) : somw[rr];
       T c2 = omw * ((T)1 + w);
       c2 = c2 < (T)1e-10 ? (T)1e-10 : c2;
       const T f = F<T>::sqrt(c2) * F<T>::rsqrt(gg);
-      const T d0 = (T)1 - mu0;
       const T zd = w * d0 - f * gm;
       const T coef = dd > (T)1e-30 ? (T)2 * zd * F<T>::rcp(dd) : (T)0;
+      const T coef_mu = coef * inv;
       // retire the prefetch of the next rows BEFORE this step's store is issued (see prefetch_issue)
       if (PF && more) {
 #pragma unroll
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const bool first = (j == 0 && i == 0 && sub == 0);
-            out[i] = first ? w - coef * d0 : f * g[j][i] + coef * mu[j][i];
+            out[i] = first ? w - coef * d0 : f * g[j][i] + coef_mu * mu[j][i];
           }
           if (FAST) {
             if (sizeof(T) == 4) {
@@ -397,11 +406,10 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bool first = (chunk == 0 && i == 0);
-        const T de = first ? (T)1 - mu[j][i] : -mu[j][i];
         gg += g[j][i] * g[j][i];
-        dd += de * de;
+        dd += first ? (T)0 : mu[j][i] * mu[j][i];  // |mu|^2 without its first element
         gm += g[j][i] * mu[j][i];
-        Gd += G[j][i] * de;
+        Gd += first ? (T)0 : G[j][i] * mu[j][i];   // <G, mu> without the first element
         Gg += G[j][i] * g[j][i];
       }
     }
@@ -410,8 +418,14 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
     gm = group_allreduce_sum<LPR, T>(gm);
     Gd = group_allreduce_sum<LPR, T>(Gd);
     Gg = group_allreduce_sum<LPR, T>(Gg);
-    const T mu0 = __shfl(mu[0][0], lane - sub, 64);
+    T mu0 = __shfl(mu[0][0], lane - sub, 64);
     const T G0 = __shfl(G[0][0], lane - sub, 64);
+    // raw mean directions: work with mu_hat = mu / ||mu|| (inv = 1 / ||mu||), chain through the normalisation below
+    const T inv = p.normalize ? (T)1 / M<T>::sqrt(dd + mu0 * mu0) : (T)1;
+    mu0 *= inv;
+    gm *= inv;
+    Gd = G0 * ((T)1 - mu0) - Gd * inv;               // <G, e1 - mu_hat>
+    dd = ((T)1 - mu0) * ((T)1 - mu0) + dd * (inv * inv);
     const T w = p.w_in[row];
     const T omw = p.omw_in ? p.omw_in[row] : (T)1 - w;
     const T kap = p.kappa[row * p.kappa_stride];
@@ -424,21 +438,34 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
     const T zd = w * d0 - f * gm;
     const bool refl = dd > (T)1e-30;
     const T inv_dd = refl ? (T)1 / dd : (T)0;
+    // gradient rows are formed by every lane (rows past the end recompute row 0 and are not stored), so that the
+    // cross-lane sum below runs with the whole wave active
+    T out[P][4];
+    T dot = 0;  // <mu_hat, d mu_hat>
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const int chunk = j * LPR + sub;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool first = (chunk == 0 && i == 0);
+        const T zp = first ? w : f * g[j][i];
+        const T mh = mu[j][i] * inv;
+        const T de = first ? d0 : -mh;
+        out[j][i] = (T)2 * (zp * Gd + zd * G[j][i] - (T)2 * zd * Gd * de * inv_dd) * inv_dd;
+        dot += out[j][i] * mh;
+      }
+    }
+    if (p.normalize) {  // wave-uniform: d mu = (d mu_hat - mu_hat <mu_hat, d mu_hat>) / ||mu||
+      dot = group_allreduce_sum<LPR, T>(dot);
+#pragma unroll
+      for (int j = 0; j < P; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[j][i] = (out[j][i] - mu[j][i] * inv * dot) * inv;
+    }
     if (valid) {
       T* drow = p.dmu + row * (int64_t)m;
 #pragma unroll
-      for (int j = 0; j < P; ++j) {
-        const int chunk = j * LPR + sub;
-        T out[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bool first = (chunk == 0 && i == 0);
-          const T zp = first ? w : f * g[j][i];
-          const T de = first ? d0 : -mu[j][i];
-          out[i] = (T)2 * (zp * Gd + zd * G[j][i] - (T)2 * zd * Gd * de * inv_dd) * inv_dd;
-        }
-        store4<T, VEC>(drow, 4 * chunk, m, out);
-      }
+      for (int j = 0; j < P; ++j) store4<T, VEC>(drow, 4 * (j * LPR + sub), m, out[j]);
       if (sub == 0) {
         const T Gp0 = G0 - (T)2 * Gd * inv_dd * d0;
         const T S = Gg + (T)2 * Gd * gm * inv_dd;
@@ -506,13 +533,15 @@ template <typename T>
 static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, void* z,
                          void* w_out, void* omw_out, int32_t* accept_idx, void* logp_out, int64_t n, int m,
                          const void* prop_e, const void* prop_u, int n_prop, const void* gauss, int max_prop,
-                         uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t s) {
+                         uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int flags,
+                         hipStream_t s) {
   FwdParams<T> p = {};
   p.mu = (const T*)mu; p.kappa = (const T*)kappa; p.z = (T*)z;
   p.w_out = (T*)w_out; p.omw_out = (T*)omw_out; p.accept_idx = accept_idx; p.logp = (T*)logp_out;
   p.prop_e = (const T*)prop_e; p.prop_u = (const T*)prop_u; p.gauss = (const T*)gauss;
   p.n = n; p.row0 = row0; p.mu_stride = (int)mu_stride; p.kappa_stride = (int)kappa_stride; p.m = m;
   p.max_prop = prop_e ? n_prop : max_prop;
+  p.normalize = (flags & VMF_FLAG_NORMALIZE_MU) ? 1 : 0;
   p.ka = make_philox_arg(seed, offset, offset_dev);
   const bool vec = (m % 4 == 0) && (mu_stride % 4 == 0) && aligned16(mu) && aligned16(z) && (!gauss || aligned16(gauss));
   const int chunks = (m + 3) / 4;
@@ -535,7 +564,7 @@ static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   if (logp_out && sizeof(T) == 8)
     hipLaunchKernelGGL(vmf_log_norm_kernel<T>, dim3(vmf_grid_for(n, 256)), dim3(256), 0, s, (const T*)kappa,
                        kappa_stride, (T*)logp_out, n, make_vmf_dim(m));
-  if (full && !prop_e) launch_fwd<T, 2>(p, grid, s);
+  if (full && !prop_e && !p.normalize) launch_fwd<T, 2>(p, grid, s);
   else if (vec) launch_fwd<T, 1>(p, grid, s);
   else launch_fwd<T, 0>(p, grid, s);
   return VMF_OK;
@@ -544,8 +573,8 @@ static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
 extern "C" int vmf_rsample_fwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, void* z,
                                void* w_out, void* omw_out, int32_t* accept_idx, void* logp_out, int64_t n, int m,
                                const void* prop_e, const void* prop_u, int n_prop, const void* gauss, int max_prop,
-                               uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int dtype,
-                               vmf_stream_t stream) {
+                               uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int flags,
+                               int dtype, vmf_stream_t stream) {
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
   VMF_REQUIRE(m >= 2, VMF_ERR_BAD_ARG, "m=%d < 2", m);
   VMF_REQUIRE(m <= 2048, VMF_ERR_UNSUPPORTED, "m=%d > 2048 is not supported", m);
@@ -563,7 +592,7 @@ extern "C" int vmf_rsample_fwd(const void* mu, int64_t mu_stride, const void* ka
   int rc;
   VMF_DISPATCH_DTYPE(dtype, rc = rsample_fwd_t<T>(mu, mu_stride, kappa, kappa_stride, z, w_out, omw_out, accept_idx,
                                                   logp_out, n, m, prop_e, prop_u, n_prop, gauss, max_prop, row0,
-                                                  seed, offset, offset_dev, (hipStream_t)stream));
+                                                  seed, offset, offset_dev, flags, (hipStream_t)stream));
   if (rc) return rc;
   return vmf_check_launch("vmf_rsample_fwd");
 }
@@ -571,8 +600,10 @@ extern "C" int vmf_rsample_fwd(const void* mu, int64_t mu_stride, const void* ka
 template <typename T>
 static int rsample_bwd_t(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, const void* w,
                          const void* omw, const void* gz, const void* gauss, void* dmu, void* dkappa, int64_t n,
-                         int m, uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t s) {
+                         int m, uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int flags,
+                         hipStream_t s) {
   GenParams<T> p = {};
+  p.normalize = (flags & VMF_FLAG_NORMALIZE_MU) ? 1 : 0;
   p.mu = (const T*)mu; p.mu_stride = mu_stride; p.kappa = (const T*)kappa; p.kappa_stride = kappa_stride;
   p.gauss = (const T*)gauss; p.n = n; p.m = m; p.row0 = row0; p.ka = make_philox_arg(seed, offset, offset_dev);
   p.dim = make_vmf_dim(m);
@@ -595,7 +626,7 @@ static int rsample_bwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
 extern "C" int vmf_rsample_bwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride,
                                const void* w, const void* omw, const void* grad_z, const void* gauss, void* dmu,
                                void* dkappa, int64_t n, int m, uint64_t row0, uint64_t seed, uint64_t offset,
-                               const uint64_t* offset_dev, int dtype, vmf_stream_t stream) {
+                               const uint64_t* offset_dev, int flags, int dtype, vmf_stream_t stream) {
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
   VMF_REQUIRE(m >= 2, VMF_ERR_BAD_ARG, "m=%d < 2", m);
   VMF_REQUIRE(m <= 2048, VMF_ERR_UNSUPPORTED, "m=%d > 2048 is not supported", m);
@@ -605,7 +636,7 @@ extern "C" int vmf_rsample_bwd(const void* mu, int64_t mu_stride, const void* ka
   VMF_REQUIRE(mu && kappa && w && grad_z && dmu && dkappa, VMF_ERR_BAD_ARG, "vmf_rsample_bwd: null pointer");
   int rc;
   VMF_DISPATCH_DTYPE(dtype, rc = rsample_bwd_t<T>(mu, mu_stride, kappa, kappa_stride, w, omw, grad_z, gauss, dmu,
-                                                  dkappa, n, m, row0, seed, offset, offset_dev, (hipStream_t)stream));
+                                                  dkappa, n, m, row0, seed, offset, offset_dev, flags, (hipStream_t)stream));
   if (rc) return rc;
   return vmf_check_launch("vmf_rsample_bwd");
 }

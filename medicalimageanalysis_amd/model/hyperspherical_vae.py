@@ -49,9 +49,19 @@ class HypersphericalVAE(nn.Module):
         return self.function_x_mu(h)
 
     def forward(self, x):
-        posteriori_params = self.encode(x)
-        z = self.reparemetrize(posteriori_params)
-        return z, self.decode(z), posteriori_params
+        """encode -> sample -> decode.  The sampler takes the raw output of the mean head and normalises it inside its
+        kernels (forward and backward), so the (B, latent_dim) tensor is not read and rewritten by a separate
+        normalisation pass; the posterior parameters returned are the same (unit z_mu, kappa) that encode() gives."""
+        h = F.softplus(self.encoder_function(x), beta=self.sftbeta)
+        for layer in self.encoder_linear_layers:
+            h = F.softplus(layer(h), beta=self.sftbeta)
+        raw = self.function_z_mu(h)
+        z_kappa = F.softplus(self.function_z_logvar(h)).squeeze(-1) + 1
+        q_z = VonMisesFisher(raw, z_kappa, validate_args=False, normalize_loc=True)
+        z = q_z.rsample()
+        with torch.no_grad():  # reporting only: the KL term depends on kappa alone
+            z_mu = F.normalize(raw, dim=-1)
+        return z, self.decode(z), (z_mu, z_kappa)
 
     def _elbo(self, x, x_mu, posteriori_params):
         z_mu, z_kappa = posteriori_params

@@ -322,7 +322,8 @@ class VonMisesFisher3DLogProb(VonMisesFisher3D):
 # ---- general m ---------------------------------------------------------------------------------------------
 class _VMFRSample(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mu, kappa, n, mu_stride, kappa_stride, max_prop, row0, seed, offset, want_logp, offset_dev=None):
+    def forward(ctx, mu, kappa, n, mu_stride, kappa_stride, max_prop, row0, seed, offset, want_logp, offset_dev=None,
+                flags=0):
         dev = _lib.require_hip(mu, kappa)
         m = mu.shape[-1]
         muc, kc = mu.detach().contiguous(), kappa.detach().contiguous()
@@ -333,12 +334,13 @@ class _VMFRSample(torch.autograd.Function):
         with torch.cuda.device(dev):
             rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(muc), mu_stride, _lib.ptr(kc), kappa_stride, _lib.ptr(z),
                                             _lib.ptr(w), _lib.ptr(omw), None, _lib.ptr(logp), n, m, None, None, 0,
-                                            None, max_prop, row0, seed, offset, _lib.ptr(offset_dev), _lib.dtype_code(muc),
+                                            None, max_prop, row0, seed, offset, _lib.ptr(offset_dev), flags,
+                                            _lib.dtype_code(muc),
                                             _lib.stream_ptr(dev))
         _lib.check(rc, "vmf_rsample_fwd")
         ctx.save_for_backward(muc, kc, w, omw)
         ctx.meta = (n, m, mu_stride, kappa_stride, row0, seed, offset, mu.shape, kappa.shape)
-        ctx.offset_dev = offset_dev
+        ctx.offset_dev, ctx.flags = offset_dev, flags
         if want_logp:
             ctx.mark_non_differentiable(logp)
             return z, logp
@@ -355,14 +357,14 @@ class _VMFRSample(torch.autograd.Function):
         with torch.cuda.device(dev):
             rc = _lib.lib().vmf_rsample_bwd(_lib.ptr(muc), mu_stride, _lib.ptr(kc), kappa_stride, _lib.ptr(w),
                                             _lib.ptr(omw), _lib.ptr(gzc), None, _lib.ptr(dmu), _lib.ptr(dk), n, m,
-                                            row0, seed, offset, _lib.ptr(ctx.offset_dev), _lib.dtype_code(muc),
+                                            row0, seed, offset, _lib.ptr(ctx.offset_dev), ctx.flags, _lib.dtype_code(muc),
                                             _lib.stream_ptr(dev))
         _lib.check(rc, "vmf_rsample_bwd")
         if mu_stride == 0:
             dmu = dmu.sum(0, keepdim=True)
         if kappa_stride == 0:
             dk = dk.sum(0, keepdim=True)
-        return (dmu.view(mu_shape), dk.view(k_shape)) + (None,) * 9
+        return (dmu.view(mu_shape), dk.view(k_shape)) + (None,) * 10
 
 
 class _VMFLogProb(torch.autograd.Function):
@@ -420,6 +422,10 @@ class VonMisesFisher(Distribution):
     m == 3, sampler/von_mises_fisher.py:28).
 
     loc (..., m) is the mean direction (expected unit-norm), scale (...) or (..., 1) the concentration.
+    With `normalize_loc=True` loc may be any non-zero vectors (e.g. the raw output of a linear layer): the sampler
+    kernels use loc / ||loc|| and return the gradient with respect to the raw rows, so no separate normalisation
+    pass (and no pass for its backward) runs over the (n, m) tensor; `.loc` then is the normalised tensor, built
+    lazily with torch ops only if log_prob / mean / argument validation ask for it.
     rsample: Wood's rejection sampler for w = <z, e1>, a uniform tangent direction from m-1 Gaussians, and the
     Householder reflection that moves e1 onto loc; all noise is Philox4x32-10 generated inside the kernel and
     keyed by the global row index (`row_offset` + row), so row-sharded ranks reproduce the unsharded draw."""
@@ -428,9 +434,12 @@ class VonMisesFisher(Distribution):
     support = constraints.real  # type: ignore
     has_rsample = True
 
-    def __init__(self, loc, scale, validate_args=None, max_proposals=64, row_offset=0, generator=None):
+    def __init__(self, loc, scale, validate_args=None, max_proposals=64, row_offset=0, generator=None,
+                 normalize_loc=False):
         assert loc.shape[-1] >= 2, "VonMisesFisher needs an ambient dimension of at least 2."
-        self.loc = loc
+        self.normalize_loc = bool(normalize_loc)
+        self._loc_given = loc
+        self._loc_unit = None if self.normalize_loc else loc
         self.scale = scale
         self.device = loc.device
         self.dtype = loc.dtype
@@ -441,9 +450,15 @@ class VonMisesFisher(Distribution):
         super().__init__(batch_shape=loc.shape[:-1], event_shape=loc.shape[-1:],
                          validate_args=_capture_safe(validate_args, loc))
 
+    @property
+    def loc(self):
+        if self._loc_unit is None:
+            self._loc_unit = torch.nn.functional.normalize(self._loc_given, dim=-1, eps=0.0)
+        return self._loc_unit
+
     def _kappa_rows(self):
         k = self.scale.to(self.dtype)
-        if k.dim() == self.loc.dim() and k.shape[-1] == 1:
+        if k.dim() == self._loc_given.dim() and k.shape[-1] == 1:
             k = k.squeeze(-1)
         return k.expand(self.batch_shape).reshape(-1)
 
@@ -451,7 +466,7 @@ class VonMisesFisher(Distribution):
         sample_shape = torch.Size(sample_shape)
         nb, S = _numel(self.batch_shape), _numel(sample_shape)
         n = nb * S
-        mu2d = self.loc.reshape(nb, self.m)
+        mu2d = self._loc_given.reshape(nb, self.m)  # raw rows when normalize_loc: the kernel normalises
         kap = self._kappa_rows()
         if nb == 1 and S > 1:
             mu_stride, kappa_stride = 0, 0          # one shared mean: nothing is replicated in memory
@@ -466,7 +481,8 @@ class VonMisesFisher(Distribution):
             z = torch.empty(out_shape + (self.m,), device=self.device, dtype=self.dtype)
             return (z, z.new_empty(out_shape)) if return_log_prob else z
         res = _VMFRSample.apply(mu2d, kap, n, mu_stride, kappa_stride, self.max_proposals, self.row_offset, seed,
-                                offset, bool(return_log_prob), offset_dev)
+                                offset, bool(return_log_prob), offset_dev,
+                                _lib.FLAG_NORMALIZE_MU if self.normalize_loc else 0)
         if return_log_prob:
             z, logp = res
             return z.view(out_shape + (self.m,)), logp.view(out_shape)
@@ -483,7 +499,7 @@ class VonMisesFisher(Distribution):
         xb = x.to(self.dtype).expand(bshape + (self.m,)).reshape(n, self.m)
         mub = self.loc.expand(bshape + (self.m,)).reshape(n, self.m)
         k = self.scale.to(self.dtype)
-        if k.dim() == self.loc.dim() and k.shape[-1] == 1:
+        if k.dim() == self._loc_given.dim() and k.shape[-1] == 1:
             k = k.squeeze(-1)
         kb = k.expand(bshape).reshape(n)
         if n == 0:

@@ -71,7 +71,7 @@ def close_vmf3(z, z_ref, tag, loc, scale, u, eps, ss=()):
 
 def test_library_loaded_is_in_tree():
     assert os.path.dirname(_lib.library_path()).endswith("medicalimageanalysis_amd")
-    assert _lib.lib().vmf_version() == 110
+    assert _lib.lib().vmf_version() == 120
 
 
 # ---- VonMisesFisher3D ---------------------------------------------------------------------------------------
@@ -488,7 +488,7 @@ def _call_rsample_pre(mu, kappa, pe, pu, ga, dtype):
     idx = torch.empty(n, device=DEV, dtype=torch.int32)
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(tmu), m, _lib.ptr(tk), 1, _lib.ptr(z), _lib.ptr(w), None,
                                     C.c_void_p(idx.data_ptr()), None, n, m, _lib.ptr(tpe), _lib.ptr(tpu), pe.shape[1],
-                                    _lib.ptr(tga), 0, 0, 0, 0, None, _lib.dtype_code(z), _lib.stream_ptr(DEV))
+                                    _lib.ptr(tga), 0, 0, 0, 0, None, 0, _lib.dtype_code(z), _lib.stream_ptr(DEV))
     _lib.check(rc, "vmf_rsample_fwd")
     torch.cuda.synchronize()
     return N(z), N(w), N(idx)
@@ -532,7 +532,7 @@ def test_general_rsample_philox_vs_oracle(oracle, tag, m, n):
     w = torch.empty(n, device=DEV, dtype=TD[tag])
     idx = torch.empty(n, device=DEV, dtype=torch.int32)
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(tmu), m, _lib.ptr(tk), 1, _lib.ptr(z), _lib.ptr(w), None,
-                                    C.c_void_p(idx.data_ptr()), None, n, m, None, None, 0, None, 64, row0, seed, off, None,
+                                    C.c_void_p(idx.data_ptr()), None, n, m, None, None, 0, None, 64, row0, seed, off, None, 0,
                                     _lib.dtype_code(z), _lib.stream_ptr(DEV))
     _lib.check(rc, "vmf_rsample_fwd")
     z, w, idx = N(z), N(w), N(idx)
@@ -547,7 +547,7 @@ def test_general_rsample_philox_vs_oracle(oracle, tag, m, n):
     z2 = torch.empty((b - a, m), device=DEV, dtype=TD[tag])
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(tmu[a:b].contiguous()), m, _lib.ptr(tk[a:b].contiguous()), 1,
                                     _lib.ptr(z2), None, None, None, None, b - a, m, None, None, 0, None, 64, row0 + a,
-                                    seed, off, None, _lib.dtype_code(z2), _lib.stream_ptr(DEV))
+                                    seed, off, None, 0, _lib.dtype_code(z2), _lib.stream_ptr(DEV))
     _lib.check(rc, "vmf_rsample_fwd shard")
     assert np.array_equal(N(z2), z[a:b])
 
@@ -601,7 +601,7 @@ def test_general_rsample_full_size_properties():
     w = torch.empty(n, device=DEV)
     idx = torch.empty(n, device=DEV, dtype=torch.int32)
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(z), _lib.ptr(w), None,
-                                    C.c_void_p(idx.data_ptr()), None, n, m, None, None, 0, None, 64, 0, 99, 0, None,
+                                    C.c_void_p(idx.data_ptr()), None, n, m, None, None, 0, None, 64, 0, 99, 0, None, 0,
                                     _lib.VMF_F32, _lib.stream_ptr(DEV))
     _lib.check(rc, "vmf_rsample_fwd")
     assert float((z.norm(dim=-1) - 1).abs().max()) < 1e-4
@@ -614,7 +614,7 @@ def test_general_rsample_full_size_properties():
     a = n - 1000
     z2 = torch.empty((1000, m), device=DEV)
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(mu[a:]), m, _lib.ptr(kappa[a:]), 1, _lib.ptr(z2), None, None, None, None,
-                                    1000, m, None, None, 0, None, 64, a, 99, 0, None, _lib.VMF_F32, _lib.stream_ptr(DEV))
+                                    1000, m, None, None, 0, None, 64, a, 99, 0, None, 0, _lib.VMF_F32, _lib.stream_ptr(DEV))
     _lib.check(rc, "vmf_rsample_fwd")
     assert torch.equal(z2, z[a:])
 
@@ -721,6 +721,41 @@ def test_spherical_vae_train_step_batch128():
     os.environ.pop("VMF_RNG")
 
 
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("m", [2, 3, 10, 64, 130, 512])
+def test_general_rsample_normalises_raw_mean_inside_the_kernel(tag, m):
+    """normalize_loc=True: raw rows (any positive norm) give the same sample as their unit rows given explicitly, and
+    the gradient with respect to the raw rows equals autograd's through F.normalize + the unit-row kernel"""
+    gen = torch.Generator(device=DEV).manual_seed(40 + m)
+    dt = TD[tag]
+    n = 777
+    raw = torch.randn(n, m, device=DEV, dtype=dt, generator=gen) * \
+        torch.exp(torch.randn(n, 1, device=DEV, dtype=dt, generator=gen) * 1.5)
+    kappa = torch.exp(torch.rand(n, device=DEV, dtype=dt, generator=gen) * np.log(1e3))
+    c = torch.randn(n, m, device=DEV, dtype=dt, generator=gen)
+    a_raw, a_k = raw.clone().requires_grad_(), kappa.clone().requires_grad_()
+    qa = VonMisesFisher(a_raw, a_k, validate_args=False, generator=rng.PhiloxGenerator(3, 7), normalize_loc=True)
+    za, lpa = qa.rsample(return_log_prob=True)
+    (za * c).sum().backward()
+    b_raw, b_k = raw.clone().requires_grad_(), kappa.clone().requires_grad_()
+    unit = torch.nn.functional.normalize(b_raw, dim=-1, eps=0.0)
+    qb = VonMisesFisher(unit, b_k, validate_args=False, generator=rng.PhiloxGenerator(3, 7))
+    zb, lpb = qb.rsample(return_log_prob=True)
+    (zb * c).sum().backward()
+    tol = dict(rtol=0, atol=1e-11) if tag == "f64" else dict(rtol=0, atol=1e-4)  # the fp32 contract
+    np.testing.assert_allclose(N(za), N(zb), **tol)
+    np.testing.assert_allclose(N(za.double().norm(dim=-1)), 1.0, atol=1e-12 if tag == "f64" else 1e-5)
+    np.testing.assert_allclose(N(lpa), N(lpb), rtol=1e-9 if tag == "f64" else 1e-4, atol=1e-9 if tag == "f64" else 2e-3)
+    scale = float(b_raw.grad.abs().max())
+    np.testing.assert_allclose(N(a_raw.grad), N(b_raw.grad), rtol=1e-8 if tag == "f64" else 2e-3,
+                               atol=(1e-10 if tag == "f64" else 2e-4) * scale)
+    np.testing.assert_allclose(N(a_k.grad), N(b_k.grad), rtol=1e-8 if tag == "f64" else 2e-3,
+                               atol=(1e-10 if tag == "f64" else 2e-4) * float(b_k.grad.abs().max()))
+    # the lazily built .loc is the unit tensor; log_prob / mean use it
+    np.testing.assert_allclose(N(qa.loc), N(unit), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(N(qa.log_prob(za.detach())), N(qb.log_prob(za.detach())), rtol=1e-5, atol=1e-4)
+
+
 def test_circle_counter_noise_backward_regenerates_the_forward_sign():
     """m = 2 with in-kernel noise: two proposals per Philox call and a one-bit tangent.  The backward pass
     regenerates that bit; check it against autograd through the forward restated in torch with the accepted proposal
@@ -787,13 +822,13 @@ def test_general_backward_vs_autograd_of_restated_forward(m):
     omw = torch.empty(n, device=DEV, dtype=torch.float64)
     mud, kd = mu.detach().contiguous(), kappa.detach().contiguous()
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(mud), m, _lib.ptr(kd), 1, _lib.ptr(zk), _lib.ptr(w), _lib.ptr(omw), None,
-                                    None, n, m, _lib.ptr(pe), _lib.ptr(pu), 4, _lib.ptr(ga), 0, 0, 0, 0, None, _lib.VMF_F64,
+                                    None, n, m, _lib.ptr(pe), _lib.ptr(pu), 4, _lib.ptr(ga), 0, 0, 0, 0, None, 0, _lib.VMF_F64,
                                     _lib.stream_ptr(DEV))
     _lib.check(rc, "fwd")
     dmu = torch.empty_like(mud)
     dk = torch.empty_like(kd)
     rc = _lib.lib().vmf_rsample_bwd(_lib.ptr(mud), m, _lib.ptr(kd), 1, _lib.ptr(w), _lib.ptr(omw), _lib.ptr(c),
-                                    _lib.ptr(ga), _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 0, 0, None, _lib.VMF_F64,
+                                    _lib.ptr(ga), _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 0, 0, None, 0, _lib.VMF_F64,
                                     _lib.stream_ptr(DEV))
     _lib.check(rc, "bwd")
     mu2, k2 = mud.clone().requires_grad_(), kd.clone().requires_grad_()
@@ -1171,7 +1206,7 @@ def test_error_conventions():
     z = VonMisesFisher3D(torch.randn(0, 3, device=DEV), torch.ones(0, device=DEV)).rsample()
     assert z.shape == (0, 3)
     rc = _lib.lib().vmf_rsample_fwd(None, 64, None, 1, None, None, None, None, None, 10, 64, None, None, 0, None, 64, 0,
-                                    0, 0, None, 0, None)
+                                    0, 0, None, 0, 0, None)
     assert rc == -1 and b"null" in _lib.lib().vmf_last_error_string()
     rc = _lib.lib().vmf_ive_fwd(0.5, _lib.ptr(loc), _lib.ptr(loc), 4, 7, None)
     assert rc == -2

@@ -54,7 +54,7 @@ def main():
 
         def f():
             rc = lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(z), None, None, None, _lib.ptr(lp), n, m,
-                                     None, None, 0, None, 64, 0, 1, 0, None, _lib.dtype_code(mu), sp)
+                                     None, None, 0, None, 64, 0, 1, 0, None, 0, _lib.dtype_code(mu), sp)
             assert rc == 0
         ms = timeit(f)
         row(f"rsample fwd m={m} n=2^{int(np.log2(n))} {str(dt)[6:]}" + (" + fused log_prob" if logp else ""), ms,
@@ -63,14 +63,14 @@ def main():
             w = torch.empty(n, device=DEV)
             omw = torch.empty(n, device=DEV)
             lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(z), _lib.ptr(w), _lib.ptr(omw), None, None, n, m,
-                                None, None, 0, None, 64, 0, 1, 0, None, _lib.VMF_F32, sp)
+                                None, None, 0, None, 64, 0, 1, 0, None, 0, _lib.VMF_F32, sp)
             gz = torch.randn_like(mu)
             dmu = torch.empty_like(mu)
             dk = torch.empty(n, device=DEV)
 
             def fb():
                 rc = lib.vmf_rsample_bwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(w), _lib.ptr(omw), _lib.ptr(gz), None,
-                                         _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 1, 0, None, _lib.VMF_F32, sp)
+                                         _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 1, 0, None, 0, _lib.VMF_F32, sp)
                 assert rc == 0
             ms = timeit(fb)
             row("rsample bwd m=64 n=2^24 float32 (noise regenerated)", ms, n * (3 * m + 3) * 4, n, "rows")
@@ -224,7 +224,7 @@ def main():
 
     def f5():
         rc = lib.vmf_rsample_fwd(_lib.ptr(mu), 2, _lib.ptr(kap), 1, _lib.ptr(z), None, None, None, None, n, 2, None, None,
-                                 0, None, 64, 0, 1, 0, None, _lib.VMF_F32, sp)
+                                 0, None, 64, 0, 1, 0, None, 0, _lib.VMF_F32, sp)
         assert rc == 0
     ms = timeit(f5, reps=5, warm=2)
     row("T^16: vMF m=2, 2^23 x 16 circles fp32", ms, n * 20, n, "circle draws")
