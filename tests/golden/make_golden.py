@@ -32,6 +32,7 @@ Files written (all float arrays keep the dtype the reference computed in):
                   CircularVAE._elbo CNN_experiment/circular_VAE.py:90-116), with gradients; _build_torus
                   (model/torus_vae.py:60-81) and latent_loss (dataloader/utils.py:101-180) by their formulas
                   evaluated with torch ops + autograd (their modules import geomstats, not installed)
+  g_curvature.npz compute_curvature_profile  regular_cnn/geometry.py:5-64 on a seeded S1_VAE
 """
 import importlib
 import os
@@ -362,6 +363,26 @@ def make_s1():
     np.savez_compressed(os.path.join(OUT, "g_s1.npz"), **out)
 
 
+def make_curvature():
+    """regular_cnn/geometry.py:5-64 executed on a seeded S1_VAE (weights stored, so the test rebuilds the model)"""
+    s1 = _import_from(os.path.join(REF, "regular_cnn"), "s1_vae")
+    sys.path.insert(0, os.path.join(REF, "regular_cnn"))
+    try:
+        geo = importlib.import_module("geometry")
+    finally:
+        sys.path.pop(0)
+    out = {}
+    # fp32 only: the reference's thetas are torch.linspace's default dtype, so a double model raises there
+    for dt, tag in ((torch.float32, "f32"),):
+        torch.manual_seed(5)
+        model = s1.S1_VAE(input_dim=7, hidden_dim=12).to(dt)
+        thetas, prof = geo.compute_curvature_profile(model, "cpu", num_points=45)
+        out[f"thetas_{tag}"], out[f"profile_{tag}"] = np.asarray(thetas), np.asarray(prof)
+        for k, v in model.state_dict().items():
+            out[f"w_{tag}::" + k] = np_(v)
+    np.savez_compressed(os.path.join(OUT, "g_curvature.npz"), **out)
+
+
 def _latent_loss_formula(labels, z, dataset, R=None, r=None):
     """dataloader/utils.py:101-180 evaluated with the same torch operations, in the same order"""
     if dataset == "S1_dataset":
@@ -462,6 +483,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["consumers"]:
         make_consumers()
         sys.exit(0)
+    if sys.argv[1:] == ["curvature"]:
+        make_curvature()
+        sys.exit(0)
     make_rsample()
     make_grads()
     make_kl()
@@ -471,6 +495,7 @@ if __name__ == "__main__":
     make_cvae()
     make_s1()
     make_consumers()
+    make_curvature()
     total = 0
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
