@@ -18,7 +18,7 @@ import os
 import sys
 
 
-def stats(src, dst):
+def stats(src, dst, timed_steps=50):
     f = glob.glob(os.path.join(src, "**", "*_kernel_stats.csv"), recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     with open(dst, "w", newline="") as out:
@@ -27,6 +27,20 @@ def stats(src, dst):
         for r in rows:
             w.writerow([r["Name"][:100], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
                         r["MaxNs"]])
+    # the kernel-trace of the same run: per-dispatch durations of the sampler kernel, so that the warm-up launches
+    # (the clocks settle over the first ~10) can be told from the timed ones
+    tr = glob.glob(os.path.join(src, "**", "*_kernel_trace.csv"), recursive=True)
+    if tr:
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(tr[0]))
+             if "vmf_rsample_fwd" in r["Kernel_Name"]]
+        if d:
+            timed = d[-timed_steps:] if timed_steps and len(d) > timed_steps else d
+            with open(dst, "a", newline="") as out:
+                w = csv.writer(out)
+                w.writerow([])
+                w.writerow(["vmf_rsample_fwd per-dispatch ns (launch order)"] + d)
+                w.writerow([f"mean of the last {len(timed)} dispatches (the timed steps) ns", sum(timed) / len(timed)])
+            print("timed-step mean ms", sum(timed) / len(timed) / 1e6)
     print("wrote", dst)
 
 
