@@ -178,11 +178,15 @@ VMF_HD float log_ive_pos_f32(float v, float lgam_v1, float x) {
     }
     return v * ::logf(0.5f * x) - lgam_v1 - x + ::logf(sum);
   }
-  const float r = ::sqrtf(v * v + x * x);
-  const float p = v / r;
-  const float rmx = v * v / (r + x);
-  const float expo = rmx - v * ::log1pf((v + rmx) / x);
-  const float p2 = p * p, pv = 1.0f / r;
+  // Debye branch with the hardware log2 / reciprocal / rsqrt: this runs once per row inside the streaming sampler
+  // (fused log_prob), where the libm versions cost 13 % more vector instructions per launch
+  const float r2 = v * v + x * x;
+  const float ir = fast_rsqrt(r2);          // 1 / r
+  const float r = r2 * ir;
+  const float p = v * ir;
+  const float rmx = v * v * fast_rcp(r + x);
+  const float expo = rmx - v * fast_log(1.0f + (v + rmx) * fast_rcp(x));
+  const float p2 = p * p;
   float pk = 1.0f, sum = 0.0f;
 #pragma unroll
   for (int k = 0; k < VMF_DEBYE_K_F32; ++k) {
@@ -190,9 +194,9 @@ VMF_HD float log_ive_pos_f32(float v, float lgam_v1, float x) {
 #pragma unroll
     for (int j = k; j >= 0; --j) poly = poly * p2 + (float)DEBYE_U[k][j];
     sum += pk * poly;
-    pk *= pv;
+    pk *= ir;
   }
-  return expo - 0.5f * ::logf(6.28318530717958647692f * r) + ::logf(sum);
+  return expo - 0.5f * fast_log(6.28318530717958647692f * r) + fast_log(sum);
 }
 
 // vMF constants that depend on m only (host side)
@@ -221,7 +225,7 @@ VMF_HD double vmf_log_norm(const VmfDim& d, double k) {
 }
 // the same in single precision (|error| ~ 1e-6 (1 + |log C_m|)); used when the output tensor is fp32
 VMF_HD float vmf_log_norm_f32v(float v, float lg_v1, float half_m_log2pi, float k) {
-  return v * ::logf(k) - half_m_log2pi - (log_ive_pos_f32(v, lg_v1, k) + k);
+  return v * fast_log(k) - half_m_log2pi - (log_ive_pos_f32(v, lg_v1, k) + k);
 }
 VMF_HD float vmf_log_norm_f32(const VmfDim& d, float k) {
   return vmf_log_norm_f32v((float)d.v, (float)d.lg_v1, (float)d.half_m_log2pi, k);

@@ -130,6 +130,50 @@ template <> struct M<double> {
   static __device__ __forceinline__ void sincospi2(double u, double* s, double* c) { ::sincospi(2.0 * u, s, c); }
 };
 
+// ---- single-precision fast math usable from host and device code (the device side maps to one hardware instruction
+//      each; the host side, used only by the host-side checks of the same formulas, to libm) ----------------------
+VMF_HD float fast_exp2(float x) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __builtin_amdgcn_exp2f(x);
+#else
+  return ::exp2f(x);
+#endif
+}
+VMF_HD float fast_log2(float x) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __builtin_amdgcn_logf(x);
+#else
+  return ::log2f(x);
+#endif
+}
+// e^x: the product x * log2(e) is split so that its rounding error (up to 1e-5 relative at |x| ~ 88) is fed back
+VMF_HD float fast_exp(float x) {
+  const float L2E = 1.44269504088896341f, L2E_LO = 1.925963033500097e-8f;  // log2(e) = L2E + L2E_LO in fp32 pairs
+  const float t = x * L2E;
+  // beyond the exponent range the result is 0 or inf whatever r is (and an infinite t would make r NaN)
+  const float r = ::fabsf(t) < 256.0f ? ::fmaf(x, L2E, -t) + x * L2E_LO : 0.0f;
+  return fast_exp2(t) * (1.0f + 0.69314718056f * r);
+}
+// a / b through the hardware reciprocal (1 ulp) instead of the IEEE division sequence (~10 instructions)
+VMF_HD float fast_rcp(float x) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __builtin_amdgcn_rcpf(x);
+#else
+  // the hardware reciprocal has no denormal results: mimic that so host-side checks see what the device computes
+  const float r = 1.0f / x;
+  return ::fabsf(r) < 1.17549435e-38f ? ::copysignf(0.0f, r) : r;
+#endif
+}
+VMF_HD float fast_log(float x) { return 0.69314718055994530942f * fast_log2(x); }
+
+VMF_HD float fast_rsqrt(float x) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __builtin_amdgcn_rsqf(x);
+#else
+  return 1.0f / ::sqrtf(x);
+#endif
+}
+
 // ---- hot-path math: hardware transcendentals for float, the accurate library for double --------------------
 // v_log_f32 / v_exp_f32 / v_sqrt_f32 / v_rsq_f32 / v_rcp_f32 are 1-ulp single instructions; v_sin_f32 / v_cos_f32
 // take their argument in revolutions, which is exactly what Box-Muller's 2 pi u needs (no range reduction).

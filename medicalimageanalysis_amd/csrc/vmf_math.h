@@ -163,39 +163,7 @@ VMF_HD T kl_value(T kappa, int variant, const KlBessel& kb, T* grad) {
 // S^1 form, two double Chebyshev sums); the streams over kappa then run at a few percent of the memory rate.  For
 // fp32 tensors the contract is 1e-4 relative, which the hardware exp2 / log2 and single-precision series meet with
 // two orders of magnitude to spare.  The stable m = 2 form keeps the double path (k A - k cancels for large k).
-VMF_HD float fast_exp2(float x) {
-#ifdef __HIP_DEVICE_COMPILE__
-  return __builtin_amdgcn_exp2f(x);
-#else
-  return ::exp2f(x);
-#endif
-}
-VMF_HD float fast_log2(float x) {
-#ifdef __HIP_DEVICE_COMPILE__
-  return __builtin_amdgcn_logf(x);
-#else
-  return ::log2f(x);
-#endif
-}
-// e^x: the product x * log2(e) is split so that its rounding error (up to 1e-5 relative at |x| ~ 88) is fed back
-VMF_HD float fast_exp(float x) {
-  const float L2E = 1.44269504088896341f, L2E_LO = 1.925963033500097e-8f;  // log2(e) = L2E + L2E_LO in fp32 pairs
-  const float t = x * L2E;
-  // beyond the exponent range the result is 0 or inf whatever r is (and an infinite t would make r NaN)
-  const float r = ::fabsf(t) < 256.0f ? ::fmaf(x, L2E, -t) + x * L2E_LO : 0.0f;
-  return fast_exp2(t) * (1.0f + 0.69314718056f * r);
-}
-// a / b through the hardware reciprocal (1 ulp) instead of the IEEE division sequence (~10 instructions)
-VMF_HD float fast_rcp(float x) {
-#ifdef __HIP_DEVICE_COMPILE__
-  return __builtin_amdgcn_rcpf(x);
-#else
-  // the hardware reciprocal has no denormal results: mimic that so host-side checks see what the device computes
-  const float r = 1.0f / x;
-  return ::fabsf(r) < 1.17549435e-38f ? ::copysignf(0.0f, r) : r;
-#endif
-}
-VMF_HD float fast_log(float x) { return 0.69314718055994530942f * fast_log2(x); }
+// (fast_exp2 / fast_log2 / fast_exp / fast_rcp / fast_log live in common.h)
 
 // sinh and cosh of k >= 0 with sinhf's overflow point (k > 89.416): Taylor below 1 (no cancellation), the two
 // exponentials up to 10, exp(k - ln 2) beyond (sinh = cosh to 2e-9 there)
