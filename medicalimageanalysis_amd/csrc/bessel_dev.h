@@ -64,10 +64,12 @@ VMF_HD double log_ive_debye(double v, double x) {
   double rmx = v * v / (r + x);                 // r - x without cancellation
   double expo = rmx - v * ::log1p((v + rmx) / x);  // v*eta - x
   double p2 = p * p, pv = 1.0 / r, pk = 1.0, sum = 0.0;  // p/v = 1/r
-#pragma unroll
+  // rolled loops on purpose: the indices are uniform, so the 91 coefficients arrive through scalar loads; unrolled,
+  // they become 182 vector registers of immediates and the elementwise kernels drop to one wave per SIMD
+#pragma unroll 1
   for (int k = 0; k < DEBYE_K; ++k) {
     double poly = 0.0;
-#pragma unroll
+#pragma unroll 1
     for (int j = k; j >= 0; --j) poly = poly * p2 + DEBYE_U[k][j];
     sum += pk * poly;
     pk *= pv;
@@ -88,6 +90,7 @@ VMF_HD double log_ive_pos(double v, double lgam_v1, double x) {
 VMF_HD double cheb_sum(const double* c, int n, double t) {
   double b0 = 0.0, b1 = 0.0;
   const double t2 = 2.0 * t;
+#pragma unroll 1
   for (int k = n - 1; k >= 1; --k) {
     const double b = c[k] + t2 * b0 - b1;
     b1 = b0;

@@ -133,9 +133,11 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // Second launch bound = waves per SIMD: the fp32 streaming shapes fit 8 waves (<= 64 VGPRs) without spilling once the
-// compiler is told to; the other instantiations keep the default.
+// compiler is told to; the narrow fp32 shapes (m <= 16) sit two registers above the 6-wave step without the hint; the
+// other instantiations keep the default.
 template <typename T, int LPR, int P, int MODE>
-__global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2) ? 8 : 1) void vmf_rsample_fwd_kernel(FwdParams<T> p) {
+__global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2) ? 8 : ((sizeof(T) == 4 && LPR <= 4) ? 6 : 1))
+void vmf_rsample_fwd_kernel(FwdParams<T> p) {
   constexpr bool VEC = MODE >= 1;
   constexpr bool FAST = MODE == 2;
   const PhiloxKey key = philox_resolve(p.ka);  // scalar: seed + host offset (+ device-resident offset)

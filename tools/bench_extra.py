@@ -18,7 +18,7 @@ from medicalimageanalysis_amd.sampler.von_mises_fisher import VonMisesFisher, Vo
 DEV = torch.device("cuda:0")
 
 
-def timeit(fn, reps=10, warm=3):
+def timeit(fn, reps=10, warm=10):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -226,15 +226,15 @@ def main():
         rc = lib.vmf_rsample_fwd(_lib.ptr(mu), 2, _lib.ptr(kap), 1, _lib.ptr(z), None, None, None, None, n, 2, None, None,
                                  0, None, 64, 0, 1, 0, None, 0, _lib.VMF_F32, sp)
         assert rc == 0
-    ms = timeit(f5, reps=5, warm=2)
+    ms = timeit(f5, reps=10, warm=10)
     row("T^16: vMF m=2, 2^23 x 16 circles fp32", ms, n * 20, n, "circle draws")
 
     def f6():
         rc = lib.vmf_s1_projnormal_fwd(_lib.ptr(mu), _lib.ptr(kap), None, _lib.ptr(z), n, 2, 0, 1, 0, None, _lib.VMF_F32, sp)
         assert rc == 0
-    ms = timeit(f6, reps=5, warm=2)
+    ms = timeit(f6, reps=10, warm=10)
     row("S^1 projected normal 2^27 rows fp32", ms, n * 20, n, "rows")
-    ms = timeit(lambda: klmod.kl_sum(kap, "s1"), reps=5, warm=2)
+    ms = timeit(lambda: klmod.kl_sum(kap, "s1"), reps=10, warm=10)
     row("KL sum (S^1, I1/I0) 2^27 fp32", ms, n * 4, n, "elems")
     del mu, kap, z
     torch.cuda.empty_cache()
@@ -243,7 +243,7 @@ def main():
     n = 1 << 24
     x = torch.exp(torch.rand(n, device=DEV, generator=g, dtype=torch.float64) * np.log(1e5))
     for v in (0.5, 31.0, 255.0):
-        ms = timeit(lambda: ive(v, x), reps=5, warm=1)
+        ms = timeit(lambda: ive(v, x), reps=10, warm=10)
         row(f"ive({v}, z) n=2^24 fp64 forward", ms, n * 16, n, "evals")
     xr = x.clone().requires_grad_()
     y = ive(31.0, xr)
@@ -251,7 +251,7 @@ def main():
     def fbw():
         xr.grad = None
         y.backward(torch.ones_like(y), retain_graph=True)
-    ms = timeit(fbw, reps=5, warm=1)
+    ms = timeit(fbw, reps=10, warm=10)
     row("ive(31, z) n=2^24 fp64 backward", ms, n * 24, n, "evals")
 
 
