@@ -7,7 +7,7 @@
 //   m > 256.  A wave therefore moves 64/LPR rows per step with fully coalesced 1 KiB loads and stores, and
 //   the three row reductions (|g|^2, |e1-mu|^2, <g,mu>) are DPP butterflies inside the LPR-lane group: no
 //   LDS traffic, no atomics.
-//   Each wave owns ONE tile of TILE_ROWS consecutive rows (grid = all tiles; workgroups are dispatched in index
+//   Each wave owns ONE tile of tile_rows(LPR) consecutive rows (grid = all tiles; workgroups are dispatched in index
 //   order, so the waves resident at any moment stream neighbouring memory).  Phase 1 (one row per lane) runs the rejection
 //   sampler for the tile's rows: lanes whose proposal was accepted retire the row (w goes to the wave's LDS
 //   slab) and are refilled with the next unassigned row of the tile through a ballot + prefix popcount, so
@@ -25,12 +25,20 @@
 #ifndef VMF_WAVES
 #define VMF_WAVES 4
 #endif
-constexpr int TILE_ROWS = VMF_TILE_ROWS;
 constexpr int WAVES = VMF_WAVES;
-// Consecutive tiles per wave: 1 for every shape.  Narrow rows make small tiles (128 rows x 20 B for m = 2), but
-// walking 4-8 tiles per wave measured 10-20 % SLOWER there (m = 2: 0.217 -> 0.258 ms, m = 10: 0.464 -> 0.508 ms for
-// 2^24 rows): more waves in flight beat fewer wave launches.
-constexpr int tiles_per_wave(int) { return 1; }
+// Rows per tile.  The rejection phase ends with a tail in which the last few rows of the tile wait for their
+// acceptance on a mostly idle wave; its cost is per tile, so narrow rows, whose phase 2 is short, take larger tiles:
+// 384 rows for m <= 4 (one lane per row) and 320 for m <= 16.  Measured on 2^27 / 2^24 rows against 128-row tiles:
+// m = 2 1.66 -> 1.22 ms, m = 3 0.259 -> 0.211, m = 4 0.220 -> 0.179, m = 8 .. 16 -4 .. -10 %.  512-row tiles are
+// slower again (the LDS slabs then limit the resident waves), and walking several 128-row tiles per wave was 10-20 %
+// slower than one (more waves in flight beat fewer wave launches).
+#ifndef VMF_TILE_ROWS_LPR1
+#define VMF_TILE_ROWS_LPR1 384
+#endif
+#ifndef VMF_TILE_ROWS_NARROW
+#define VMF_TILE_ROWS_NARROW 320
+#endif
+constexpr int tile_rows(int lpr) { return lpr == 1 ? VMF_TILE_ROWS_LPR1 : (lpr <= 4 ? VMF_TILE_ROWS_NARROW : VMF_TILE_ROWS); }
 constexpr uint32_t SLOT_GAUSS = 0x10000u;
 constexpr int BWD_STEPS = 16;
 
@@ -141,6 +149,7 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
   constexpr bool VEC = MODE >= 1;
   constexpr bool FAST = MODE == 2;
   const PhiloxKey key = philox_resolve(p.ka);  // scalar: seed + host offset (+ device-resident offset)
+  constexpr int TILE_ROWS = tile_rows(LPR);
   __shared__ T s_w[WAVES][TILE_ROWS];
   __shared__ T s_omw[WAVES][TILE_ROWS];
   // fp32 fused log_prob: log C_m(kappa) and kappa of the tile's rows (kappa is read from HBM once per row)
@@ -161,13 +170,10 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
   float* const slc = s_lc[sizeof(T) == 4 ? wave : 0];
   float* const skp = s_kp[sizeof(T) == 4 ? wave : 0];
 
-  constexpr int TPW = tiles_per_wave(LPR);
-#pragma unroll 1
-  for (int tw = 0; tw < TPW; ++tw) {
-    const int64_t tile = ((int64_t)blockIdx.x * WAVES + wave) * TPW + tw;
+  {
+    const int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
     const int64_t tile0 = tile * TILE_ROWS;  // wave-uniform
     const int64_t left = p.n - tile0;
-    if (TPW > 1 && left <= 0) break;
     const int ntile = left <= 0 ? 0 : (left < TILE_ROWS ? (int)left : TILE_ROWS);
     const T* const kap_t = p.kappa + tile0 * p.kappa_stride;
     const uint64_t grow0 = p.row0 + (uint64_t)tile0;
@@ -193,7 +199,6 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
       int my = lane, next = 64, k = 0;
       bool active = my < ntile;
       T a = 0, b = 0, d = 0;
-      U4 rc = {0u, 0u, 0u, 0u};  // circle: the current call's four words
       bool neg = false;           // circle: the row's sign bit
       if (active) {
         if (pre) wood_consts<T>(kap_t[my * p.kappa_stride], m, &a, &b, &d);
@@ -207,12 +212,17 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
             const int64_t row = tile0 + my;
             acc = wood_try<T>(a, b, d, m, p.prop_e[row * p.max_prop + k], p.prop_u[row * p.max_prop + k], &w, &omw);
           } else if (LPR == 1 && circle) {
-            if ((k & 1) == 0) {
-              rc = philox4x32_10(grow0 + (uint64_t)my, (uint32_t)(k >> 1), key);
-              if (k == 0) neg = (rc.x & 1u) != 0u;
-            }
-            acc = wood_try_counter<T>(b, 2, (T)0.5, u01<T>((k & 1) ? rc.z : rc.x), u01<T>((k & 1) ? rc.w : rc.y),
-                                      &w, &omw);
+            // k is even here: both proposals of call k / 2 are evaluated in this iteration and the first accepted
+            // one wins (the same decision sequence as one proposal per iteration, in half the Philox calls -- lanes
+            // of a wave sit at different k, so skipping the call on odd k would not shorten the wave's iteration)
+            const U4 rc = philox4x32_10(grow0 + (uint64_t)my, (uint32_t)(k >> 1), key);
+            if (k == 0) neg = (rc.x & 1u) != 0u;
+            T w1, omw1;
+            const bool a0 = wood_try_counter<T>(b, 2, (T)0.5, u01<T>(rc.x), u01<T>(rc.y), &w, &omw);
+            const bool a1 = wood_try_counter<T>(b, 2, (T)0.5, u01<T>(rc.z), u01<T>(rc.w), &w1, &omw1);
+            const bool use0 = a0 || k + 1 >= p.max_prop;
+            acc = use0 || a1;
+            if (!use0) { w = w1; omw = omw1; ++k; }
           } else {
             const U4 r = philox4x32_10(grow0 + (uint64_t)my, (uint32_t)k, key);
             acc = wood_try_counter<T>(b, m, u01<T>(r.x), u01<T>(r.y), u01<T>(r.z), &w, &omw);
@@ -551,10 +561,9 @@ static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   while (lpr < chunks && lpr < 64) lpr *= 2;
   const int passes = (chunks + lpr - 1) / lpr;
   const bool full = vec && (passes == 1 || passes == 2 || passes == 4 || passes == 8) && m == 4 * lpr * passes;
-  const int64_t n_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
-  const int tpw = tiles_per_wave(lpr);
-  int64_t gb = (n_tiles + (int64_t)WAVES * tpw - 1) / ((int64_t)WAVES * tpw);
-  // One tile per wave (several for narrow rows, see tiles_per_wave), every tile its own wave: workgroups are dispatched in index order, so the waves in flight at
+  const int64_t n_tiles = (n + tile_rows(lpr) - 1) / tile_rows(lpr);
+  int64_t gb = (n_tiles + WAVES - 1) / WAVES;
+  // One tile per wave, every tile its own wave: workgroups are dispatched in index order, so the waves in flight at
   // any moment work on neighbouring tiles (DRAM-page and TLB locality).  A persistent grid of 2048 workgroups walking
   // strided tiles measured 13 % slower on the same kernel body.
   VMF_REQUIRE(gb <= 0x7fffffff, VMF_ERR_UNSUPPORTED, "n=%lld rows need more than 2^31 workgroups", (long long)n);

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Narrow-row sampler shapes on one MI355X: general-m rsample for m = 2 .. 16 through the C ABI, kernel time from
+events.  These shapes are instruction-bound (a 128-row tile of m = 2 is 2.5 KiB), so this is the table to watch when the
+rejection phase or the per-row arithmetic changes.  VMF_HIP_LIB selects the library build under test.
+    python tools/bench_narrow.py [--shapes 2:27,2:24,4:24,10:24,16:24]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from medicalimageanalysis_amd import _lib  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def timeit(fn, reps=20, warm=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in ev]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="2:27,2:24,3:24,4:24,8:24,10:24,16:24")
+    ap.add_argument("--dtype", default="float32")
+    args = ap.parse_args()
+    lib = _lib.lib()
+    sp = _lib.stream_ptr(DEV)
+    dt = getattr(torch, args.dtype)
+    es = 4 if dt == torch.float32 else 8
+    g = torch.Generator(device=DEV).manual_seed(0)
+    print(f"library: {os.environ.get('VMF_HIP_LIB', 'default')}")
+    print("| m | rows | ms | algorithmic GB/s | G rows/s | mean proposals |")
+    print("|---|---|---|---|---|---|")
+    for item in args.shapes.split(","):
+        m, lg = (int(v) for v in item.split(":"))
+        n = 1 << lg
+        mu = torch.nn.functional.normalize(torch.randn(n, m, device=DEV, generator=g), dim=-1).to(dt)
+        kap = torch.exp(torch.rand(n, device=DEV, generator=g) * np.log(1e4)).to(dt)
+        z = torch.empty_like(mu)
+
+        def f():
+            rc = lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(z), None, None, None, None, n, m,
+                                     None, None, 0, None, 64, 0, 1, 0, None, 0, _lib.dtype_code(mu), sp)
+            assert rc == 0, lib.vmf_last_error_string()
+        ms = timeit(f)
+        # mean number of proposals per row on a sample of the rows
+        ns = min(n, 1 << 20)
+        acc = torch.empty(ns, device=DEV, dtype=torch.int32)
+        rc = lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(z), None, None, _lib.ptr(acc), None, ns, m,
+                                 None, None, 0, None, 64, 0, 1, 0, None, 0, _lib.dtype_code(mu), sp)
+        assert rc == 0
+        torch.cuda.synchronize()
+        mean_prop = float(acc.float().mean()) + 1.0
+        print(f"| {m} | 2^{lg} | {ms:.3f} | {n * (2 * m + 1) * es / ms / 1e6:.0f} | {n / ms / 1e6:.2f} | {mean_prop:.3f} |")
+        del mu, z, kap
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
