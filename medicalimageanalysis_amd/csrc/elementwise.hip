@@ -309,6 +309,62 @@ __global__ __launch_bounds__(256) void s1_projnormal_kernel(const T* __restrict_
   }
 }
 
+// dim == 2 (the circle, the only shape the reference's S^1 VAE uses): one 64-bit access per operand row, one Philox
+// call and one Box-Muller pair per row, everything else in registers.  Same arithmetic as the general kernel above.
+template <typename T>
+struct alignas(2 * sizeof(T)) Pair {
+  T a, b;
+};
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void s1_projnormal2_kernel(const T* __restrict__ mean, const T* __restrict__ kappa,
+                                                             const T* __restrict__ noise, const T* __restrict__ gz,
+                                                             T* __restrict__ z, T* __restrict__ dmean,
+                                                             T* __restrict__ dkappa, int64_t n, uint64_t row0,
+                                                             PhiloxArg ka) {
+  const PhiloxKey key = philox_resolve(ka);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const Pair<T> mu = reinterpret_cast<const Pair<T>*>(mean)[i];
+    const T k = kappa[i];
+    T n0, n1;
+    if (noise) {
+      const Pair<T> e = reinterpret_cast<const Pair<T>*>(noise)[i];
+      n0 = e.a; n1 = e.b;
+    } else {
+      const U4 r = philox4x32_10(row0 + (uint64_t)i, 0x30000u, key);
+      box_muller<T>(u01<T>(r.x), u01<T>(r.y), &n0, &n1);
+    }
+    const T y0 = mu.a * k + n0, y1 = mu.b * k + n1;
+    T ss = 0;
+    ss += y0 * y0;
+    ss += y1 * y1;
+    T nn = M<T>::sqrt(ss);
+    const bool clamped = nn < (T)1e-12;
+    if (clamped) nn = (T)1e-12;
+    if (!BWD) {
+      Pair<T> out;
+      out.a = y0 / nn; out.b = y1 / nn;
+      reinterpret_cast<Pair<T>*>(z)[i] = out;
+    } else {
+      const Pair<T> g = reinterpret_cast<const Pair<T>*>(gz)[i];
+      T yg = 0;
+      yg += y0 * g.a;
+      yg += y1 * g.b;
+      const T dy0 = clamped ? g.a / nn : g.a / nn - y0 * yg / (nn * nn * nn);
+      const T dy1 = clamped ? g.b / nn : g.b / nn - y1 * yg / (nn * nn * nn);
+      Pair<T> dm;
+      dm.a = k * dy0; dm.b = k * dy1;
+      reinterpret_cast<Pair<T>*>(dmean)[i] = dm;
+      T dk = 0;
+      dk += mu.a * dy0;
+      dk += mu.b * dy1;
+      dkappa[i] = dk;
+    }
+  }
+}
+template <typename T>
+static bool pair_aligned(const void* p) { return ((uintptr_t)p & (2 * sizeof(T) - 1)) == 0; }
+
 extern "C" int vmf_s1_projnormal_fwd(const void* mean, const void* kappa, const void* noise, void* z, int64_t n,
                                      int dim, uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                                      int dtype, vmf_stream_t stream) {
@@ -316,11 +372,19 @@ extern "C" int vmf_s1_projnormal_fwd(const void* mean, const void* kappa, const 
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(mean && kappa && z, VMF_ERR_BAD_ARG, "vmf_s1_projnormal_fwd: null pointer");
   PhiloxArg key = make_philox_arg(seed, offset, offset_dev);
-  int grid = vmf_grid_for(n, 256);
-  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((s1_projnormal_kernel<T, false>), dim3(grid), dim3(256), 0,
-                                               (hipStream_t)stream, (const T*)mean, (const T*)kappa,
-                                               (const T*)noise, (const T*)nullptr, (T*)z, (T*)nullptr,
-                                               (T*)nullptr, n, dim, row0, key));
+  // the circle kernel takes one row per thread up to 2^30 rows (backward: 0.87 -> 0.80 ms for 2^27 rows against a
+  // 2048-workgroup grid-stride walk; forward unchanged)
+  int grid = vmf_grid_for(n, 256, dim == 2 ? (1 << 22) : 2048);
+  VMF_DISPATCH_DTYPE(dtype, {
+    if (dim == 2 && pair_aligned<T>(mean) && pair_aligned<T>(z) && pair_aligned<T>(noise))
+      hipLaunchKernelGGL((s1_projnormal2_kernel<T, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                         (const T*)mean, (const T*)kappa, (const T*)noise, (const T*)nullptr, (T*)z, (T*)nullptr,
+                         (T*)nullptr, n, row0, key);
+    else
+      hipLaunchKernelGGL((s1_projnormal_kernel<T, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                         (const T*)mean, (const T*)kappa, (const T*)noise, (const T*)nullptr, (T*)z, (T*)nullptr,
+                         (T*)nullptr, n, dim, row0, key);
+  });
   return vmf_check_launch("vmf_s1_projnormal_fwd");
 }
 
@@ -331,10 +395,18 @@ extern "C" int vmf_s1_projnormal_bwd(const void* mean, const void* kappa, const 
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(mean && kappa && gz && dmean && dkappa, VMF_ERR_BAD_ARG, "vmf_s1_projnormal_bwd: null pointer");
   PhiloxArg key = make_philox_arg(seed, offset, offset_dev);
-  int grid = vmf_grid_for(n, 256);
-  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((s1_projnormal_kernel<T, true>), dim3(grid), dim3(256), 0,
-                                               (hipStream_t)stream, (const T*)mean, (const T*)kappa,
-                                               (const T*)noise, (const T*)gz, (T*)nullptr, (T*)dmean, (T*)dkappa,
-                                               n, dim, row0, key));
+  // the circle kernel takes one row per thread up to 2^30 rows (backward: 0.87 -> 0.80 ms for 2^27 rows against a
+  // 2048-workgroup grid-stride walk; forward unchanged)
+  int grid = vmf_grid_for(n, 256, dim == 2 ? (1 << 22) : 2048);
+  VMF_DISPATCH_DTYPE(dtype, {
+    if (dim == 2 && pair_aligned<T>(mean) && pair_aligned<T>(gz) && pair_aligned<T>(dmean) && pair_aligned<T>(noise))
+      hipLaunchKernelGGL((s1_projnormal2_kernel<T, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                         (const T*)mean, (const T*)kappa, (const T*)noise, (const T*)gz, (T*)nullptr, (T*)dmean,
+                         (T*)dkappa, n, row0, key);
+    else
+      hipLaunchKernelGGL((s1_projnormal_kernel<T, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                         (const T*)mean, (const T*)kappa, (const T*)noise, (const T*)gz, (T*)nullptr, (T*)dmean,
+                         (T*)dkappa, n, dim, row0, key);
+  });
   return vmf_check_launch("vmf_s1_projnormal_bwd");
 }

@@ -479,6 +479,63 @@ def test_s1_projected_normal(golden, oracle, tag):
     np.testing.assert_allclose(N(tk.grad).reshape(-1), dk, rtol=rt, atol=rt * np.abs(dk).max())
 
 
+def _philox_normals(oracle, rows, slot0, seed, offset, dim):
+    """the counter-based normal stream restated on the CPU: element c of a row comes from call (row, slot0 + c // 4),
+    words (0,1) -> Box-Muller pair (0,1), words (2,3) -> pair (2,3)"""
+    key = [seed & 0xffffffff, ((seed >> 32) ^ (offset >> 32)) & 0xffffffff]
+    out = np.empty((len(rows), dim))
+    for i, row in enumerate(rows):
+        vals = []
+        for ch in range((dim + 3) // 4):
+            x = oracle.philox_raw([row & 0xffffffff, row >> 32, slot0 + ch, offset & 0xffffffff], key)
+            u = [(v >> 9) * 2.0 ** -23 + 2.0 ** -24 for v in x]
+            for a, b in ((u[0], u[1]), (u[2], u[3])):
+                r = np.sqrt(-2.0 * np.log(a))
+                vals += [r * np.cos(2 * np.pi * b), r * np.sin(2 * np.pi * b)]
+        out[i] = vals[:dim]
+    return out
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("dim", [2, 3, 5])
+def test_s1_and_uniform_counter_noise_streams(oracle, tag, dim):
+    """S^1 projected normal (the dim = 2 kernel and the general one) and the uniform prior with in-kernel noise equal the
+    oracle fed with the same stream rebuilt on the CPU; row0 shifts the stream (sharded draws)"""
+    dt = torch.float64 if tag == "f64" else torch.float32
+    n, row0, seed, offset = 300, 12345, 0x1234567887654321, (7 << 32) + 99
+    gen = np.random.default_rng(dim)
+    mean = gen.standard_normal((n, dim))
+    mean /= np.linalg.norm(mean, axis=1, keepdims=True)
+    kappa = gen.uniform(0.5, 50.0, n)
+    tm, tk = T(mean, dt), T(kappa, dt)
+    z = torch.empty_like(tm)
+    lib, sp = _lib.lib(), _lib.stream_ptr(DEV)
+    _lib.check(lib.vmf_s1_projnormal_fwd(_lib.ptr(tm), _lib.ptr(tk), None, _lib.ptr(z), n, dim, row0, seed, offset, None,
+                                         _lib.dtype_code(z), sp), "vmf_s1_projnormal_fwd")
+    rows = [row0 + i for i in range(n)]
+    noise = _philox_normals(oracle, rows, 0x30000, seed, offset, dim)
+    want = oracle.s1_projnormal_fwd(N(tm).astype(np.float64), N(tk).astype(np.float64), noise)
+    tol = 1e-11 if tag == "f64" else 2e-5
+    np.testing.assert_allclose(N(z), want, rtol=0, atol=tol)
+    # backward with the noise regenerated in the kernel
+    gz = gen.standard_normal((n, dim))
+    tg = T(gz, dt)
+    dm, dk = torch.empty_like(tm), torch.empty_like(tk)
+    _lib.check(lib.vmf_s1_projnormal_bwd(_lib.ptr(tm), _lib.ptr(tk), None, _lib.ptr(tg), _lib.ptr(dm), _lib.ptr(dk), n,
+                                         dim, row0, seed, offset, None, _lib.dtype_code(z), sp), "vmf_s1_projnormal_bwd")
+    wm, wk = oracle.s1_projnormal_bwd(N(tm).astype(np.float64), N(tk).astype(np.float64), noise,
+                                      N(tg).astype(np.float64))
+    rt = 1e-9 if tag == "f64" else 2e-3
+    np.testing.assert_allclose(N(dm), wm, rtol=rt, atol=rt * np.abs(wm).max())
+    np.testing.assert_allclose(N(dk).reshape(-1), wk, rtol=rt, atol=rt * np.abs(wk).max())
+    # uniform prior: normalised normals of slot family 0x20000
+    out = torch.empty_like(tm)
+    _lib.check(lib.vmf_sphere_uniform_sample(None, _lib.ptr(out), n, dim, row0, seed, offset, None, _lib.dtype_code(out),
+                                             sp), "vmf_sphere_uniform_sample")
+    gs = _philox_normals(oracle, rows, 0x20000, seed, offset, dim)
+    np.testing.assert_allclose(N(out), gs / np.linalg.norm(gs, axis=1, keepdims=True), rtol=0, atol=tol)
+
+
 # ---- general m ----------------------------------------------------------------------------------------------------
 def _call_rsample_pre(mu, kappa, pe, pu, ga, dtype):
     n, m = mu.shape

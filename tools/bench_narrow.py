@@ -35,6 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="2:27,2:24,3:24,4:24,8:24,10:24,16:24")
     ap.add_argument("--dtype", default="float32")
+    ap.add_argument("--s1", type=int, default=27, help="log2 rows of the S^1 projected-normal case (0: skip)")
     args = ap.parse_args()
     lib = _lib.lib()
     sp = _lib.stream_ptr(DEV)
@@ -67,6 +68,27 @@ def main():
         print(f"| {m} | 2^{lg} | {ms:.3f} | {n * (2 * m + 1) * es / ms / 1e6:.0f} | {n / ms / 1e6:.2f} | {mean_prop:.3f} |")
         del mu, z, kap
         torch.cuda.empty_cache()
+    if args.s1:
+        n = 1 << args.s1
+        mu = torch.nn.functional.normalize(torch.randn(n, 2, device=DEV, generator=g), dim=-1).to(dt)
+        kap = (torch.rand(n, device=DEV, generator=g) * 50 + 1).to(dt)
+        z = torch.empty_like(mu)
+        gz = torch.randn_like(mu)
+        dmu = torch.empty_like(mu)
+        dk = torch.empty_like(kap)
+
+        def f1():
+            rc = lib.vmf_s1_projnormal_fwd(_lib.ptr(mu), _lib.ptr(kap), None, _lib.ptr(z), n, 2, 0, 1, 0, None,
+                                           _lib.dtype_code(mu), sp)
+            assert rc == 0
+
+        def f2():
+            rc = lib.vmf_s1_projnormal_bwd(_lib.ptr(mu), _lib.ptr(kap), None, _lib.ptr(gz), _lib.ptr(dmu), _lib.ptr(dk),
+                                           n, 2, 0, 1, 0, None, _lib.dtype_code(mu), sp)
+            assert rc == 0
+        for name, f, b in (("S^1 projected normal fwd", f1, 5 * es), ("S^1 projected normal bwd", f2, 8 * es)):
+            ms = timeit(f)
+            print(f"| {name} | 2^{args.s1} | {ms:.3f} | {n * b / ms / 1e6:.0f} | {n / ms / 1e6:.2f} | - |")
 
 
 if __name__ == "__main__":
