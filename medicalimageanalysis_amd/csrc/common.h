@@ -289,6 +289,12 @@ __device__ __forceinline__ double block_sum_double(double x, double* red) {
   return t;
 }
 
+// one 64-bit (float) / 128-bit (double) access for a row of two values
+template <typename T>
+struct alignas(2 * sizeof(T)) Pair {
+  T a, b;
+};
+
 // 16-byte-aligned group of four values (one 128-bit access for float, two for double)
 template <typename T>
 struct alignas(sizeof(T) * 4 > 16 ? 16 : sizeof(T) * 4) Vec4 {

@@ -311,10 +311,6 @@ __global__ __launch_bounds__(256) void s1_projnormal_kernel(const T* __restrict_
 
 // dim == 2 (the circle, the only shape the reference's S^1 VAE uses): one 64-bit access per operand row, one Philox
 // call and one Box-Muller pair per row, everything else in registers.  Same arithmetic as the general kernel above.
-template <typename T>
-struct alignas(2 * sizeof(T)) Pair {
-  T a, b;
-};
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void s1_projnormal2_kernel(const T* __restrict__ mean, const T* __restrict__ kappa,
                                                              const T* __restrict__ noise, const T* __restrict__ gz,

@@ -38,6 +38,9 @@ constexpr int WAVES = VMF_WAVES;
 #ifndef VMF_TILE_ROWS_NARROW
 #define VMF_TILE_ROWS_NARROW 320
 #endif
+#ifndef VMF_TILE_ROWS_CIRCLE
+#define VMF_TILE_ROWS_CIRCLE 512
+#endif
 constexpr int tile_rows(int lpr) { return lpr == 1 ? VMF_TILE_ROWS_LPR1 : (lpr <= 4 ? VMF_TILE_ROWS_NARROW : VMF_TILE_ROWS); }
 constexpr uint32_t SLOT_GAUSS = 0x10000u;
 constexpr int BWD_STEPS = 16;
@@ -105,7 +108,8 @@ __device__ __forceinline__ void noise4(const T* __restrict__ grow_ptr, uint64_t 
 
 // Forward kernel.  MODE 0: scalar element access (m % 4 != 0 or unaligned rows), bounds checks, pre-drawn noise
 // allowed.  MODE 1: 128-bit access, bounds checks (m < 4 LPR P), pre-drawn noise allowed.  MODE 2: the streaming
-// configuration -- m == 4 LPR P exactly, 128-bit access, counter-based noise only, no per-element guards.
+// configuration -- m == 4 LPR P exactly, 128-bit access, counter-based noise only, no per-element guards.  MODE 3: the
+// circle -- m == 2 exactly, 64-bit access, counter-based noise only (LPR = P = 1).
 template <typename T>
 struct FwdParams {
   const T* mu; const T* kappa; T* z;
@@ -140,17 +144,21 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
-// Second launch bound = waves per SIMD: the fp32 streaming shapes fit 8 waves (<= 64 VGPRs) without spilling once the
-// compiler is told to; the narrow fp32 shapes (m <= 16) sit two registers above the 6-wave step without the hint; the
-// other instantiations keep the default.
+// Second launch bound = waves per SIMD: the one-pass fp32 streaming shapes (m <= 256) fit 8 waves (<= 64 VGPRs)
+// without spilling once the compiler is told to; the two-pass shape (m = 512) would spill 7 registers there and
+// measures the same at 5, 6 or 8 waves, so it asks for 6; the narrow fp32 shapes (m <= 16) sit two registers above
+// the 6-wave step without the hint; the other instantiations keep the default.
 template <typename T, int LPR, int P, int MODE>
-__global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P <= 2) ? 8 : ((sizeof(T) == 4 && LPR <= 4) ? 6 : 1))
+__global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 4 && MODE == 2 && P == 1) ? 8 : ((sizeof(T) == 4 && (LPR <= 4 || (MODE == 2 && P == 2))) ? 6 : 1))
 void vmf_rsample_fwd_kernel(FwdParams<T> p) {
-  constexpr bool VEC = MODE >= 1;
+  constexpr bool VEC = MODE == 1 || MODE == 2;
   constexpr bool FAST = MODE == 2;
+  constexpr bool CIRCLE = MODE == 3;
   const PhiloxKey key = philox_resolve(p.ka);  // scalar: seed + host offset (+ device-resident offset)
-  constexpr int TILE_ROWS = tile_rows(LPR);
-  __shared__ T s_w[WAVES][TILE_ROWS];
+  // the circle instantiation parks only 1 - w (w = 1 - (1 - w) exactly as the proposal formed it), so its tiles can be
+  // larger in the same LDS footprint
+  constexpr int TILE_ROWS = CIRCLE ? VMF_TILE_ROWS_CIRCLE : tile_rows(LPR);
+  __shared__ T s_w[WAVES][CIRCLE ? 1 : TILE_ROWS];
   __shared__ T s_omw[WAVES][TILE_ROWS];
   // fp32 fused log_prob: log C_m(kappa) and kappa of the tile's rows (kappa is read from HBM once per row)
   __shared__ float s_lc[sizeof(T) == 4 ? WAVES : 1][sizeof(T) == 4 ? TILE_ROWS : 1];
@@ -158,13 +166,14 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int RPI = 64 / LPR;  // rows per wave step
   const int sub = lane % LPR, grp = lane / LPR;
-  const int m = FAST ? 4 * LPR * P : p.m;
-  const bool pre = !FAST && p.prop_e != nullptr;
+  const int m = FAST ? 4 * LPR * P : (CIRCLE ? 2 : p.m);
+  const bool pre = !FAST && !CIRCLE && p.prop_e != nullptr;
   // Circle (m = 2) with counter noise: a proposal needs two uniforms (the Beta(1/2,1/2) angle and the accept draw)
   // and the tangent "direction" is one sign, so one Philox call serves two proposals (words x,y then z,w of call
   // k >> 1) and bit 0 of the first call's word x (below the 23 bits u01 uses) is the sign.  The sign travels to
   // phase 2 in the sign bit of the parked 1 - w (which is never negative).
-  const bool circle = LPR == 1 && !FAST && m == 2 && !pre && p.gauss == nullptr;
+  // MODE 3 is this case with m a compile-time 2 and 64-bit accesses; MODE 0 takes it when rows are not 8-byte aligned.
+  const bool circle = CIRCLE || (LPR == 1 && MODE == 0 && m == 2 && !pre && p.gauss == nullptr);
   T* const sw = s_w[wave];
   T* const somw = s_omw[wave];
   float* const slc = s_lc[sizeof(T) == 4 ? wave : 0];
@@ -229,7 +238,7 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
           }
           if (k + 1 >= p.max_prop) acc = true;  // the last proposal allowed is taken regardless
           if (acc) {
-            sw[my] = w;
+            if (!CIRCLE) sw[my] = w;
             somw[my] = (LPR == 1 && circle && neg) ? -omw : omw;
             if (p.w_out) p.w_out[tile0 + my] = w;
             if (p.omw_out) p.omw_out[tile0 + my] = omw;
@@ -255,7 +264,7 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
     // ---- phase 2: stream the tile's rows, RPI rows per step ----
     const T* const mu_t = p.mu + tile0 * p.mu_stride;
     T* const z_t = p.z + tile0 * m;
-    const T* const ga_t = (!FAST && p.gauss) ? p.gauss + tile0 * m : nullptr;
+    const T* const ga_t = (!FAST && !CIRCLE && p.gauss) ? p.gauss + tile0 * m : nullptr;
     // fp32 streaming mode keeps the NEXT step's mu rows in flight while the current step computes and stores.
     constexpr bool PF = FAST && sizeof(T) == 4;
     f32x4 pf[P], cur[P];
@@ -302,7 +311,12 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
           philox_normal4<T>(grow0 + (uint64_t)rr, SLOT_GAUSS + (uint32_t)chunk, key, g[j]);
           if (j == 0 && sub == 0) g[0][0] = (T)0;
         } else {
-          load4<T, VEC>(mrow, 4 * chunk, m, mu[j]);
+          if (CIRCLE) {
+            const Pair<T> v = *reinterpret_cast<const Pair<T>*>(mrow);
+            mu[j][0] = v.a; mu[j][1] = v.b; mu[j][2] = mu[j][3] = (T)0;
+          } else {
+            load4<T, VEC>(mrow, 4 * chunk, m, mu[j]);
+          }
           if (LPR == 1 && circle) {
             g[j][0] = g[j][2] = g[j][3] = (T)0;
             g[j][1] = __builtin_signbit(somw[rr]) ? (T)-1 : (T)1;
@@ -330,7 +344,8 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
       gm *= inv;
       const T d0 = (T)1 - mu0;
       dd = d0 * d0 + dd * (inv * inv);  // |e1 - mu|^2
-      const T w = sw[rr], omw = (LPR == 1 && circle) ? M<T>::abs(somw[rr]) : somw[rr];
+      const T omw = (LPR == 1 && circle) ? M<T>::abs(somw[rr]) : somw[rr];
+      const T w = CIRCLE ? (T)1 - omw : sw[rr];
       T c2 = omw * ((T)1 + w);
       c2 = c2 < (T)1e-10 ? (T)1e-10 : c2;
       const T f = F<T>::sqrt(c2) * F<T>::rsqrt(gg);
@@ -355,7 +370,11 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
             const bool first = (j == 0 && i == 0 && sub == 0);
             out[i] = first ? w - coef * d0 : f * g[j][i] + coef_mu * mu[j][i];
           }
-          if (FAST) {
+          if (CIRCLE) {
+            Pair<T> o;
+            o.a = out[0]; o.b = out[1];
+            *reinterpret_cast<Pair<T>*>(zrow) = o;
+          } else if (FAST) {
             if (sizeof(T) == 4) {
               // z is written once and not read again by this kernel: stream it past the caches
               f32x4 v4 = {(float)out[0], (float)out[1], (float)out[2], (float)out[3]};
@@ -575,7 +594,13 @@ static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   if (logp_out && sizeof(T) == 8)
     hipLaunchKernelGGL(vmf_log_norm_kernel<T>, dim3(vmf_grid_for(n, 256)), dim3(256), 0, s, (const T*)kappa,
                        kappa_stride, (T*)logp_out, n, make_vmf_dim(m));
-  if (full && !prop_e && !p.normalize) launch_fwd<T, 2>(p, grid, s);
+  const bool pair_ok = m == 2 && !prop_e && !gauss && mu_stride % 2 == 0 && ((uintptr_t)mu % (2 * sizeof(T))) == 0 &&
+                       ((uintptr_t)z % (2 * sizeof(T))) == 0;
+  if (pair_ok) {
+    const int64_t nt = (n + VMF_TILE_ROWS_CIRCLE - 1) / VMF_TILE_ROWS_CIRCLE;
+    hipLaunchKernelGGL((vmf_rsample_fwd_kernel<T, 1, 1, 3>), dim3((unsigned)((nt + WAVES - 1) / WAVES)), dim3(WAVES * 64), 0,
+                       s, p);
+  } else if (full && !prop_e && !p.normalize) launch_fwd<T, 2>(p, grid, s);
   else if (vec) launch_fwd<T, 1>(p, grid, s);
   else launch_fwd<T, 0>(p, grid, s);
   return VMF_OK;

@@ -607,6 +607,21 @@ def test_general_rsample_philox_vs_oracle(oracle, tag, m, n):
                                     seed, off, None, 0, _lib.dtype_code(z2), _lib.stream_ptr(DEV))
     _lib.check(rc, "vmf_rsample_fwd shard")
     assert np.array_equal(N(z2), z[a:b])
+    if m == 2:
+        # rows that are not 8-byte aligned take the element-wise kernel instead of the 64-bit circle kernel: same draws
+        es = tmu.element_size()
+        buf_mu = torch.empty(2 * n + 1, device=DEV, dtype=TD[tag])
+        buf_z = torch.empty(2 * n + 1, device=DEV, dtype=TD[tag])
+        mu_off, z_off = buf_mu[1:].view(n, 2), buf_z[1:].view(n, 2)
+        mu_off.copy_(tmu)
+        assert mu_off.data_ptr() % (2 * es) == es
+        idx3 = torch.empty(n, device=DEV, dtype=torch.int32)
+        rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(mu_off), m, _lib.ptr(tk), 1, _lib.ptr(z_off), None, None,
+                                        C.c_void_p(idx3.data_ptr()), None, n, m, None, None, 0, None, 64, row0, seed, off,
+                                        None, 0, _lib.dtype_code(z_off), _lib.stream_ptr(DEV))
+        _lib.check(rc, "vmf_rsample_fwd unaligned")
+        assert np.array_equal(N(idx3), idx)
+        np.testing.assert_allclose(N(z_off), z, rtol=0, atol=1e-12 if tag == "f64" else 1e-6)
 
 
 def test_general_rsample_distribution_ks():
