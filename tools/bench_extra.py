@@ -94,11 +94,28 @@ def main():
         row(f"VonMisesFisher3D.rsample B={n} fp32, torch noise in reference order", ms, n * 44, n, "rows")
         ms = timeit(lambda: klmod.kl_mean(kap, "spherical"))
         row(f"KL mean (spherical piecewise) n={n} fp32", ms, n * 4, n, "elems")
-    loc = torch.randn(128, 3, device=DEV, generator=g)
-    kap = torch.rand(128, 1, device=DEV, generator=g) * 99 + 1
-    q = VonMisesFisher3D(loc, kap, validate_args=False)
-    ms = timeit(lambda: q.rsample())
-    row("VonMisesFisher3D.rsample B=128 scale (B,1) -> (128,128,3)", ms, 128 * 128 * 12, 128 * 128, "rows")
+    for B in (128, 4096):  # the (B,1)-scale broadcast of the reference's VAE: the result is (B,B,3)
+        loc = torch.randn(B, 3, device=DEV, generator=g)
+        kap = torch.rand(B, 1, device=DEV, generator=g) * 99 + 1
+        q = VonMisesFisher3D(loc, kap, validate_args=False)
+        for mode in ("philox", "torch"):
+            os.environ["VMF_RNG"] = mode
+            ms = timeit(lambda: q.rsample())
+            row(f"VonMisesFisher3D.rsample B={B} scale (B,1) -> ({B},{B},3), {mode} noise (incl. python)", ms,
+                B * B * (12 if mode == "philox" else 28), B * B, "rows")
+        if B == 4096:
+            zq = q.rsample().detach().requires_grad_(False)
+            lq = loc.clone().requires_grad_()
+            kq = kap.clone().requires_grad_()
+            gzq = torch.randn_like(zq)
+
+            def fbq():
+                lq.grad = kq.grad = None
+                VonMisesFisher3D(lq, kq, validate_args=False).rsample().backward(gzq)
+            ms = timeit(fbq)
+            row(f"  forward + backward of the same (B={B})", ms, B * B * (12 + 28 + 12 + 16), B * B, "rows")
+            del zq, gzq
+    os.environ["VMF_RNG"] = "torch"
 
     # --- Spherical-VAE train step, batch 128, 28x28 inputs, latent m = 3: this package vs the same step written with
     #     torch ops following the reference's formulas (what the reference executes on a GPU)

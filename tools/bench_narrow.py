@@ -43,8 +43,8 @@ def main():
     es = 4 if dt == torch.float32 else 8
     g = torch.Generator(device=DEV).manual_seed(0)
     print(f"library: {os.environ.get('VMF_HIP_LIB', 'default')}")
-    print("| m | rows | ms | algorithmic GB/s | G rows/s | mean proposals |")
-    print("|---|---|---|---|---|---|")
+    print("| m | rows | fwd ms | algorithmic GB/s | G rows/s | mean proposals | bwd ms | bwd GB/s |")
+    print("|---|---|---|---|---|---|---|---|")
     for item in args.shapes.split(","):
         m, lg = (int(v) for v in item.split(":"))
         n = 1 << lg
@@ -65,8 +65,22 @@ def main():
         assert rc == 0
         torch.cuda.synchronize()
         mean_prop = float(acc.float().mean()) + 1.0
-        print(f"| {m} | 2^{lg} | {ms:.3f} | {n * (2 * m + 1) * es / ms / 1e6:.0f} | {n / ms / 1e6:.2f} | {mean_prop:.3f} |")
-        del mu, z, kap
+        # backward: reads mu, grad_z, kappa, w, 1 - w; writes dmu, dkappa (noise regenerated)
+        w, omw = torch.empty(n, device=DEV, dtype=dt), torch.empty(n, device=DEV, dtype=dt)
+        rc = lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(z), _lib.ptr(w), _lib.ptr(omw), None, None, n, m,
+                                 None, None, 0, None, 64, 0, 1, 0, None, 0, _lib.dtype_code(mu), sp)
+        assert rc == 0
+        gz = torch.randn_like(mu)
+        dmu, dk = torch.empty_like(mu), torch.empty_like(kap)
+
+        def fb():
+            rc = lib.vmf_rsample_bwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(w), _lib.ptr(omw), _lib.ptr(gz), None,
+                                     _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 1, 0, None, 0, _lib.dtype_code(mu), sp)
+            assert rc == 0, lib.vmf_last_error_string()
+        msb = timeit(fb)
+        print(f"| {m} | 2^{lg} | {ms:.3f} | {n * (2 * m + 1) * es / ms / 1e6:.0f} | {n / ms / 1e6:.2f} | {mean_prop:.3f} "
+              f"| {msb:.3f} | {n * (3 * m + 4) * es / msb / 1e6:.0f} |")
+        del mu, z, kap, gz, dmu, dk, w, omw
         torch.cuda.empty_cache()
     if args.s1:
         n = 1 << args.s1
@@ -88,7 +102,7 @@ def main():
             assert rc == 0
         for name, f, b in (("S^1 projected normal fwd", f1, 5 * es), ("S^1 projected normal bwd", f2, 8 * es)):
             ms = timeit(f)
-            print(f"| {name} | 2^{args.s1} | {ms:.3f} | {n * b / ms / 1e6:.0f} | {n / ms / 1e6:.2f} | - |")
+            print(f"| {name} | 2^{args.s1} | {ms:.3f} | {n * b / ms / 1e6:.0f} | {n / ms / 1e6:.2f} | - | - | - |")
 
 
 if __name__ == "__main__":
