@@ -86,13 +86,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # VMF_BENCH_FORCE_DIST=1 runs the process-group path (RCCL init, barriers, the max-reduce of the time) with a single
+    # rank too: the rehearsal of the multi-GPU code path that fits a one-GPU box
+    use_dist = world > 1 or os.environ.get("VMF_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if use_dist:
         if a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -127,7 +130,7 @@ def main():
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
@@ -137,11 +140,11 @@ def main():
         step(a.warmup + i)
         evs[i][1].record(stream)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -203,7 +206,7 @@ def main():
         if world == 1 and a.cpu_rows > 0:
             out["cpu_baseline"] = cpu_baseline(m, a.cpu_rows, seed, a.log_prob)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
