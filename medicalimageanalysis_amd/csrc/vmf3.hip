@@ -37,6 +37,7 @@ extern "C" const char* vmf_last_error_string(void) { return g_err; }
 struct Bcast {
   int ndim;
   int identity;  // every operand is indexed by the output row itself
+  int small;     // the result has fewer than 2^31 rows: the index is decomposed with 32-bit divisions
   int64_t odims[8], w_str[8], k_str[8], l_str[8], e_str[8];
 };
 
@@ -47,6 +48,18 @@ __device__ __forceinline__ void unravel(const Bcast& bc, int64_t o, int64_t* wi,
     return;
   }
   int64_t a = 0, b = 0, c = 0, d = 0;
+  if (bc.small) {  // a 64-bit division costs several times the rest of the row's arithmetic
+    uint32_t o32 = (uint32_t)o;
+    for (int dm = bc.ndim - 1; dm >= 0; --dm) {
+      const uint32_t dim = (uint32_t)bc.odims[dm];
+      const uint32_t q = o32 / dim;
+      const int64_t idx = (int64_t)(o32 - q * dim);
+      o32 = q;
+      a += idx * bc.w_str[dm]; b += idx * bc.k_str[dm]; c += idx * bc.l_str[dm]; d += idx * bc.e_str[dm];
+    }
+    *wi = a; *ki = b; *li = c; *ei = d;
+    return;
+  }
   for (int dm = bc.ndim - 1; dm >= 0; --dm) {
     int64_t q = o / bc.odims[dm];
     int64_t idx = o - q * bc.odims[dm];
@@ -81,6 +94,7 @@ static int make_bcast(Bcast* bc, int64_t* n_out, int ndim, const int64_t* odims,
     s *= odims[d];
   }
   bc->identity = ident;
+  bc->small = n < ((int64_t)1 << 31);
   *n_out = n;
   return VMF_OK;
 }
