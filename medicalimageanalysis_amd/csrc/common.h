@@ -44,6 +44,33 @@ static inline int vmf_grid_for(int64_t work_items, int block, int max_blocks = 2
   return (int)g;
 }
 
+// Workgroup i runs on XCD i % 8 (round-robin dispatch), each XCD with its own L2 and translation cache.  This remap
+// gives every XCD one contiguous eighth of the forward kernel's tile blocks instead of every eighth block, so that an
+// XCD streams through one region of mu and z.  Measured on 2^24 x 64 fp32 (A/B in one process, both orders twice):
+// 1.681-1.685 ms plain, 1.635-1.649 ms with eighths; sixteenths the same, 32 / 64 regions 1.654 / 1.662, short runs
+// per XCD worse than plain (runs of 16 blocks: 1.794, 128: 1.688, 1024: 1.670).  m = 256 / 512: -4 % / -2.5 %; rows of
+// <= 16 elements, the backward and the log_prob kernels measure the same either way and keep the plain order.
+// The thread-per-row S^1 kernel is 3-7 % slower with it (0.64 -> 0.67 ms forward for 2^27 rows) and keeps the plain order.
+// VMF_XCD_RUN: -1 plain order, 0 grid / 2^VMF_XCD_SHIFT blocks per run, > 0 that many blocks per run.
+#ifndef VMF_XCD_SHIFT
+#define VMF_XCD_SHIFT 3
+#endif
+#ifndef VMF_XCD_RUN
+#define VMF_XCD_RUN 0
+#endif
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
+#if VMF_XCD_RUN < 0
+  return b;
+#else
+  const uint32_t run = VMF_XCD_RUN > 0 ? (uint32_t)VMF_XCD_RUN : nb >> VMF_XCD_SHIFT;
+  const uint32_t span = run << 3;
+  const uint32_t base = span ? (b / span) * span : 0u;
+  if (span == 0u || base + span > nb) return b;  // the ragged end of the grid keeps the plain order
+  const uint32_t r = b - base;
+  return base + (r & 7u) * run + (r >> 3);
+#endif
+}
+
 // ---- Philox4x32-10 --------------------------------------------------------------------------
 struct PhiloxKey {
   uint32_t k0, k1, c3;  // key words and the 4th counter word (offset_lo)
