@@ -75,8 +75,17 @@ def cpu_baseline(m, rows, seed, log_prob):
         dt = time.perf_counter() - t0
         if dt >= 10.0 or passes >= 200:
             break
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {"value": rows * passes / dt, "unit": "samples/s", "cores": int(orc.lib().orc_num_threads()),
-            "kind": "port",
+            "kind": "port", "cpu_model": cpu_model, "host_cpus": os.cpu_count(),
             "sample": f"{passes} passes over {rows} rows of the same workload (m={m}, fp32, oracle's Philox"
                       + (", + log_prob" if log_prob else "") + f"), {dt:.1f} s"}
 

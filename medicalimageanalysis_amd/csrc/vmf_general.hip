@@ -453,7 +453,7 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
     T mu0 = __shfl(mu[0][0], lane - sub, 64);
     const T G0 = __shfl(G[0][0], lane - sub, 64);
     // raw mean directions: work with mu_hat = mu / ||mu|| (inv = 1 / ||mu||), chain through the normalisation below
-    const T inv = p.normalize ? (T)1 / M<T>::sqrt(dd + mu0 * mu0) : (T)1;
+    const T inv = p.normalize ? F<T>::rsqrt(dd + mu0 * mu0) : (T)1;
     mu0 *= inv;
     gm *= inv;
     Gd = G0 * ((T)1 - mu0) - Gd * inv;               // <G, e1 - mu_hat>
@@ -464,12 +464,15 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
     T c2 = omw * ((T)1 + w);
     const bool inside = c2 >= (T)1e-10;
     c2 = inside ? c2 : (T)1e-10;
-    const T sq = M<T>::sqrt(c2), gn = M<T>::sqrt(gg);
-    const T f = sq / gn;
+    // F<T>: the 1-ulp hardware sqrt / reciprocal for fp32 (as in the forward), the accurate library for fp64.
+    // With IEEE divisions and square roots the fp32 backward measured 2.70 ms instead of 2.50 (2^24 x 64).
+    const T sq = F<T>::sqrt(c2), gn = F<T>::sqrt(gg);
+    const T rgn = F<T>::rcp(gn);
+    const T f = sq * rgn;
     const T d0 = (T)1 - mu0;
     const T zd = w * d0 - f * gm;
     const bool refl = dd > (T)1e-30;
-    const T inv_dd = refl ? (T)1 / dd : (T)0;
+    const T inv_dd = refl ? F<T>::rcp(dd) : (T)0;
     // gradient rows are formed by every lane (rows past the end recompute row 0 and are not stored), so that the
     // cross-lane sum below runs with the whole wave active
     T out[P][4];
@@ -497,18 +500,28 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
     if (valid) {
       T* drow = p.dmu + row * (int64_t)m;
 #pragma unroll
-      for (int j = 0; j < P; ++j) store4<T, VEC>(drow, 4 * (j * LPR + sub), m, out[j]);
+      for (int j = 0; j < P; ++j) {
+        // d mu is written once and not read again here: stream it past the caches (fp32 128-bit path)
+        if (VEC && sizeof(T) == 4) {
+          if (4 * (j * LPR + sub) < m) {
+            f32x4 v4 = {(float)out[j][0], (float)out[j][1], (float)out[j][2], (float)out[j][3]};
+            __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(drow + 4 * (j * LPR + sub)));
+          }
+        } else {
+          store4<T, VEC>(drow, 4 * (j * LPR + sub), m, out[j]);
+        }
+      }
       if (sub == 0) {
         const T Gp0 = G0 - (T)2 * Gd * inv_dd * d0;
         const T S = Gg + (T)2 * Gd * gm * inv_dd;
-        const T dw = Gp0 + (inside ? S / gn * (-w / sq) : (T)0);
+        const T dw = Gp0 + (inside ? S * rgn * (-w * F<T>::rcp(sq)) : (T)0);
         const T m1 = (T)(m - 1);
-        const T c = M<T>::sqrt((T)4 * kap * kap + m1 * m1);
-        const T b = m1 / ((T)2 * kap + c);
-        const T e = omw / (((T)1 + b) - w * ((T)1 - b));
+        const T c = F<T>::sqrt((T)4 * kap * kap + m1 * m1);
+        const T b = m1 * F<T>::rcp((T)2 * kap + c);
+        const T e = omw * F<T>::rcp(((T)1 + b) - w * ((T)1 - b));
         const T den = (T)1 - ((T)1 - b) * e;
-        const T dw_db = (T)-2 * e * ((T)1 - e) / (den * den);
-        p.dkappa[row] = dw * dw_db * ((T)-2 * b / c);
+        const T dw_db = (T)-2 * e * ((T)1 - e) * F<T>::rcp(den * den);
+        p.dkappa[row] = dw * dw_db * ((T)-2 * b * F<T>::rcp(c));
       }
     }
   }

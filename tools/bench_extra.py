@@ -47,7 +47,8 @@ def main():
                            (10, 1 << 24, torch.float32, False), (64, 1 << 22, torch.float64, False),
                            (2, 1 << 24, torch.float32, False)):
         mu = torch.nn.functional.normalize(torch.randn(n, m, device=DEV, generator=g, dtype=torch.float32), dim=-1).to(dt)
-        kap = torch.exp(torch.rand(n, device=DEV, generator=g) * np.log(1e4)).to(dt)
+        # kappa log-uniform on [1, 1e4]; the m = 512 configuration goes up to 1e5
+        kap = torch.exp(torch.rand(n, device=DEV, generator=g) * np.log(1e5 if m == 512 else 1e4)).to(dt)
         z = torch.empty_like(mu)
         lp = torch.empty(n, device=DEV, dtype=dt) if logp else None
         es = 4 if dt == torch.float32 else 8
