@@ -662,6 +662,34 @@ def test_general_rsample_two_sample_ks_against_cpu_sampler(oracle):
             assert p > 1e-3, (m, kappa, comp, p)
 
 
+@pytest.mark.parametrize("m", [64, 2, 10])
+def test_general_rsample_every_row_written_once_for_any_grid(m):
+    """the forward kernel walks its tiles in a remapped block order (one contiguous eighth of the grid per XCD, plain
+    order for the ragged end): for grids of 1 .. 8k+r blocks every row must be produced exactly once -- the output is
+    pre-filled with NaN, and the same rows drawn as two shards (other grid sizes, other remaps) must give the same bits"""
+    rows_per_block = {64: 4 * 128, 2: 4 * 512, 10: 4 * 320}[m]
+    lib, sp = _lib.lib(), _lib.stream_ptr(DEV)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for nb in (1, 7, 8, 9, 15, 16, 17, 63, 64, 65, 1003):
+        n = nb * rows_per_block - 5
+        mu = torch.nn.functional.normalize(torch.randn(n, m, device=DEV, generator=g), dim=-1)
+        kappa = torch.exp(torch.rand(n, device=DEV, generator=g) * np.log(1e3))
+        z = torch.full((n, m), float("nan"), device=DEV)
+        _lib.check(lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(z), None, None, None, None, n, m, None,
+                                       None, 0, None, 64, 0, 7, 3, None, 0, _lib.VMF_F32, sp), "vmf_rsample_fwd")
+        assert bool(torch.isfinite(z).all()), (m, nb)
+        assert float((z.norm(dim=-1) - 1).abs().max()) < 1e-4
+        cut = (n // 3) | 1
+        parts = []
+        for a0, b0 in ((0, cut), (cut, n)):
+            zp = torch.full((b0 - a0, m), float("nan"), device=DEV)
+            _lib.check(lib.vmf_rsample_fwd(_lib.ptr(mu[a0:b0]), m, _lib.ptr(kappa[a0:b0]), 1, _lib.ptr(zp), None, None, None,
+                                           None, b0 - a0, m, None, None, 0, None, 64, a0, 7, 3, None, 0, _lib.VMF_F32, sp),
+                       "vmf_rsample_fwd shard")
+            parts.append(zp)
+        assert torch.equal(torch.cat(parts), z), (m, nb)
+
+
 def test_general_rsample_full_size_properties():
     """the headline configuration at full size, m = 64 and 2^24 rows, through size-independent properties: unit norm,
     <z,mu> = w, E[w] = A_m(kappa), shard-invariance of the tail rows"""
@@ -669,7 +697,7 @@ def test_general_rsample_full_size_properties():
     g = torch.Generator(device=DEV).manual_seed(1)
     mu = torch.nn.functional.normalize(torch.randn(n, m, device=DEV, generator=g), dim=-1)
     kappa = torch.exp(torch.rand(n, device=DEV, generator=g) * np.log(1e4))
-    z = torch.empty_like(mu)
+    z = torch.full_like(mu, float("nan"))  # a tile that is never processed would stay NaN
     w = torch.empty(n, device=DEV)
     idx = torch.empty(n, device=DEV, dtype=torch.int32)
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(z), _lib.ptr(w), None,
