@@ -131,6 +131,12 @@ __device__ __forceinline__ T u01(uint32_t x) {
   // one shift, one convert, one fma; every step is exact
   return (T)(x >> 9) * (T)(1.0 / 8388608.0) + (T)(1.0 / 16777216.0);
 }
+// fp32: the same value in two instructions.  v_alignbit puts the 23 bits under the exponent of 1.0, giving
+// 1 + (x >> 9) 2^-23 in [1, 2); subtracting 1 - 2^-24 (the float below 1) is exact.
+template <>
+__device__ __forceinline__ float u01<float>(uint32_t x) {
+  return __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, x, 9u)) - 0.99999994f;
+}
 
 // ---- type-generic math: accurate (ocml) versions --------------------------------------------
 template <typename T> struct M;
