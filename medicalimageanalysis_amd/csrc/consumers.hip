@@ -29,7 +29,7 @@ __device__ __forceinline__ void store4_stream(double*, const double*) {}
 // loss = a_rec * sum_e (x[e mod n_x] - x_hat[e])^2 + a_kl * sum_i KL(kappa_i)
 // x is broadcast over the leading dimensions of x_hat: with kappa of shape (B, 1) the reference's sample is
 // (B, B, 3), the decoder output (B, B, D), and `x - x_mu` repeats x (B, D) along the first axis.
-template <typename T, int VEC>
+template <typename T, int VEC, bool BESSEL>
 __global__ __launch_bounds__(256) void elbo_fwd_kernel(const T* __restrict__ x, const T* __restrict__ xhat,
                                                        const T* __restrict__ kappa, double* __restrict__ partial,
                                                        int64_t n_x, int64_t n_hat, int64_t n_kappa, int variant,
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void elbo_fwd_kernel(const T* __restrict__ x, 
   }
   for (int64_t i = tid; i < n_kappa; i += nthreads) {
     T g;
-    acc_kl += (double)kl_eval<T>(kappa[i], variant, kb, &g);
+    acc_kl += (double)kl_eval<T, BESSEL>(kappa[i], variant, kb, &g);
   }
   double t0 = block_sum_double(acc_rec, red);
   __syncthreads();
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void elbo_final_kernel(const double* __restric
   }
 }
 
-template <typename T, int VEC>
+template <typename T, int VEC, bool BESSEL>
 __global__ __launch_bounds__(256) void elbo_bwd_kernel(const T* __restrict__ x, const T* __restrict__ xhat,
                                                        const T* __restrict__ kappa, const T* __restrict__ gout,
                                                        T a_rec, T a_kl, T* __restrict__ d_xhat,
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void elbo_bwd_kernel(const T* __restrict__ x, 
     const T c = a_kl * go;
     for (int64_t i = tid; i < n_kappa; i += nthreads) {
       T g;
-      kl_eval<T>(kappa[i], variant, kb, &g);
+      kl_eval<T, BESSEL>(kappa[i], variant, kb, &g);
       d_kappa[i] = c * g;
     }
   }
@@ -160,10 +160,18 @@ extern "C" int vmf_elbo_fwd(const void* x, const void* x_hat, const void* kappa,
   if (work < n_kappa) work = n_kappa;
   const int grid = vmf_grid_for(work, 256, VMF_ELBO_WORKSPACE_DOUBLES / 2);
   if (vec) {
-    hipLaunchKernelGGL((elbo_fwd_kernel<float, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x,
-                       (const float*)x_hat, (const float*)kappa, workspace, n_x, n_hat, n_kappa, variant, kb);
+    // fp32 and not the stable m = 2 form: the instantiation without the double-precision Bessel code (a third of the
+    // registers)
+    if (variant == VMF_KL_STABLE_M2)
+      hipLaunchKernelGGL((elbo_fwd_kernel<float, 4, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                         (const float*)x, (const float*)x_hat, (const float*)kappa, workspace, n_x, n_hat, n_kappa,
+                         variant, kb);
+    else
+      hipLaunchKernelGGL((elbo_fwd_kernel<float, 4, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                         (const float*)x, (const float*)x_hat, (const float*)kappa, workspace, n_x, n_hat, n_kappa,
+                         variant, kb);
   } else {
-    VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((elbo_fwd_kernel<T, 1>), dim3(grid), dim3(256), 0,
+    VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((elbo_fwd_kernel<T, 1, true>), dim3(grid), dim3(256), 0,
                                                  (hipStream_t)stream, (const T*)x, (const T*)x_hat,
                                                  (const T*)kappa, workspace, n_x, n_hat, n_kappa, variant, kb));
   }
@@ -191,11 +199,16 @@ extern "C" int vmf_elbo_bwd(const void* x, const void* x_hat, const void* kappa,
   if (d_kappa && work < n_kappa) work = n_kappa;
   const int grid = vmf_grid_for(work, 256);
   if (vec) {
-    hipLaunchKernelGGL((elbo_bwd_kernel<float, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x,
-                       (const float*)x_hat, (const float*)kappa, (const float*)grad_loss, (float)a_rec, (float)a_kl,
-                       (float*)d_x_hat, (float*)d_kappa, n_x, n_hat, n_kappa, variant, kb);
+    if (variant == VMF_KL_STABLE_M2)
+      hipLaunchKernelGGL((elbo_bwd_kernel<float, 4, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                         (const float*)x, (const float*)x_hat, (const float*)kappa, (const float*)grad_loss, (float)a_rec,
+                         (float)a_kl, (float*)d_x_hat, (float*)d_kappa, n_x, n_hat, n_kappa, variant, kb);
+    else
+      hipLaunchKernelGGL((elbo_bwd_kernel<float, 4, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                         (const float*)x, (const float*)x_hat, (const float*)kappa, (const float*)grad_loss, (float)a_rec,
+                         (float)a_kl, (float*)d_x_hat, (float*)d_kappa, n_x, n_hat, n_kappa, variant, kb);
   } else {
-    VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((elbo_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0,
+    VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((elbo_bwd_kernel<T, 1, true>), dim3(grid), dim3(256), 0,
                                                  (hipStream_t)stream, (const T*)x, (const T*)x_hat,
                                                  (const T*)kappa, (const T*)grad_loss, (T)a_rec, (T)a_kl,
                                                  (T*)d_x_hat, (T*)d_kappa, n_x, n_hat, n_kappa, variant, kb));

@@ -104,7 +104,7 @@ extern "C" int vmf_bessel_ratio_fwd(double v, const void* z, void* out, int64_t 
 // model/spherical_vae.py:153-182 with one pass; the `.mean()` of :134 is the fused two-stage sum.
 // VEC = 4: 128-bit loads / stores of four consecutive elements per lane (fp32, 16-byte aligned); the n % 4 tail is
 // taken by the first lanes with scalar accesses.
-template <typename T, int VEC>
+template <typename T, int VEC, bool BESSEL>
 __global__ __launch_bounds__(256) void kl_fwd_kernel(const T* __restrict__ kappa, T* __restrict__ out,
                                                      double* __restrict__ partial, int64_t n, int variant,
                                                      KlBessel kb) {
@@ -117,16 +117,16 @@ __global__ __launch_bounds__(256) void kl_fwd_kernel(const T* __restrict__ kappa
     const Vec4<T> k4 = *reinterpret_cast<const Vec4<T>*>(kappa + 4 * i);
     Vec4<T> o4;
     T g;
-    o4.v[0] = kl_eval<T>(k4.v[0], variant, kb, &g);
-    o4.v[1] = kl_eval<T>(k4.v[1], variant, kb, &g);
-    o4.v[2] = kl_eval<T>(k4.v[2], variant, kb, &g);
-    o4.v[3] = kl_eval<T>(k4.v[3], variant, kb, &g);
+    o4.v[0] = kl_eval<T, BESSEL>(k4.v[0], variant, kb, &g);
+    o4.v[1] = kl_eval<T, BESSEL>(k4.v[1], variant, kb, &g);
+    o4.v[2] = kl_eval<T, BESSEL>(k4.v[2], variant, kb, &g);
+    o4.v[3] = kl_eval<T, BESSEL>(k4.v[3], variant, kb, &g);
     if (out) *reinterpret_cast<Vec4<T>*>(out + 4 * i) = o4;
     acc += ((double)o4.v[0] + (double)o4.v[1]) + ((double)o4.v[2] + (double)o4.v[3]);
   }
   for (int64_t i = 4 * nvec + tid; i < n; i += stride) {
     T g;
-    T kl = kl_eval<T>(kappa[i], variant, kb, &g);
+    T kl = kl_eval<T, BESSEL>(kappa[i], variant, kb, &g);
     if (out) out[i] = kl;
     acc += (double)kl;
   }
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void kl_final_kernel(const double* __restrict_
   if (threadIdx.x == 0) *sum_out = alpha * t;
 }
 
-template <typename T, int VEC>
+template <typename T, int VEC, bool BESSEL>
 __global__ __launch_bounds__(256) void kl_bwd_kernel(const T* __restrict__ kappa, const T* __restrict__ gout,
                                                      int64_t gstride, T gscale, T* __restrict__ dkappa, int64_t n,
                                                      int variant, KlBessel kb) {
@@ -159,15 +159,15 @@ __global__ __launch_bounds__(256) void kl_bwd_kernel(const T* __restrict__ kappa
     else go.v[0] = go.v[1] = go.v[2] = go.v[3] = gout[0];
     Vec4<T> d4;
     T g;
-    kl_eval<T>(k4.v[0], variant, kb, &g); d4.v[0] = go.v[0] * gscale * g;
-    kl_eval<T>(k4.v[1], variant, kb, &g); d4.v[1] = go.v[1] * gscale * g;
-    kl_eval<T>(k4.v[2], variant, kb, &g); d4.v[2] = go.v[2] * gscale * g;
-    kl_eval<T>(k4.v[3], variant, kb, &g); d4.v[3] = go.v[3] * gscale * g;
+    kl_eval<T, BESSEL>(k4.v[0], variant, kb, &g); d4.v[0] = go.v[0] * gscale * g;
+    kl_eval<T, BESSEL>(k4.v[1], variant, kb, &g); d4.v[1] = go.v[1] * gscale * g;
+    kl_eval<T, BESSEL>(k4.v[2], variant, kb, &g); d4.v[2] = go.v[2] * gscale * g;
+    kl_eval<T, BESSEL>(k4.v[3], variant, kb, &g); d4.v[3] = go.v[3] * gscale * g;
     *reinterpret_cast<Vec4<T>*>(dkappa + 4 * i) = d4;
   }
   for (int64_t i = 4 * nvec + tid; i < n; i += stride) {
     T g;
-    kl_eval<T>(kappa[i], variant, kb, &g);
+    kl_eval<T, BESSEL>(kappa[i], variant, kb, &g);
     dkappa[i] = gout[i * gstride] * gscale * g;
   }
 }
@@ -185,10 +185,14 @@ extern "C" int vmf_kl_fwd(const void* kappa, void* out, double* sum_out, double*
   int grid = vmf_grid_for(dtype == VMF_F32 ? (n + 3) / 4 : n, 256, VMF_KL_WORKSPACE_DOUBLES);
   if (n > 0) {
     if (dtype == VMF_F32 && ew_aligned16(kappa) && ew_aligned16(out)) {
-      hipLaunchKernelGGL((kl_fwd_kernel<float, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                         (const float*)kappa, (float*)out, sum_out ? workspace : nullptr, n, variant, kb);
+      if (variant == VMF_KL_STABLE_M2)
+        hipLaunchKernelGGL((kl_fwd_kernel<float, 4, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)kappa, (float*)out, sum_out ? workspace : nullptr, n, variant, kb);
+      else
+        hipLaunchKernelGGL((kl_fwd_kernel<float, 4, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)kappa, (float*)out, sum_out ? workspace : nullptr, n, variant, kb);
     } else {
-      VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((kl_fwd_kernel<T, 1>), dim3(grid), dim3(256), 0,
+      VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((kl_fwd_kernel<T, 1, true>), dim3(grid), dim3(256), 0,
                                                    (hipStream_t)stream, (const T*)kappa, (T*)out,
                                                    sum_out ? workspace : nullptr, n, variant, kb));
     }
@@ -213,11 +217,16 @@ extern "C" int vmf_kl_bwd(const void* kappa, const void* gout, int64_t gout_stri
   KlBessel kb = make_kl_bessel();
   int grid = vmf_grid_for(n, 256);
   if (dtype == VMF_F32 && ew_aligned16(kappa) && ew_aligned16(dkappa) && (gout_stride == 0 || ew_aligned16(gout))) {
-    hipLaunchKernelGGL((kl_bwd_kernel<float, 4>), dim3(vmf_grid_for((n + 3) / 4, 256)), dim3(256), 0,
-                       (hipStream_t)stream, (const float*)kappa, (const float*)gout, gout_stride, (float)gscale,
-                       (float*)dkappa, n, variant, kb);
+    if (variant == VMF_KL_STABLE_M2)
+      hipLaunchKernelGGL((kl_bwd_kernel<float, 4, true>), dim3(vmf_grid_for((n + 3) / 4, 256)), dim3(256), 0,
+                         (hipStream_t)stream, (const float*)kappa, (const float*)gout, gout_stride, (float)gscale,
+                         (float*)dkappa, n, variant, kb);
+    else
+      hipLaunchKernelGGL((kl_bwd_kernel<float, 4, false>), dim3(vmf_grid_for((n + 3) / 4, 256)), dim3(256), 0,
+                         (hipStream_t)stream, (const float*)kappa, (const float*)gout, gout_stride, (float)gscale,
+                         (float*)dkappa, n, variant, kb);
   } else {
-    VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((kl_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0,
+    VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((kl_bwd_kernel<T, 1, true>), dim3(grid), dim3(256), 0,
                                                  (hipStream_t)stream, (const T*)kappa, (const T*)gout, gout_stride,
                                                  (T)gscale, (T*)dkappa, n, variant, kb));
   }

@@ -88,9 +88,17 @@ static inline KlBessel make_kl_bessel() {
   return b;
 }
 
-template <typename T>
+// BESSEL = false leaves the two forms that need the double-precision Bessel code out (they return NaN): the fp32
+// kernels use it as the per-element fall-back of the fast forms below, where those two variants only fall back for a
+// NaN kappa (S^1) or are not dispatched at all (stable m = 2) -- and without the Bessel code the kernels need a third
+// of the registers.
+template <typename T, bool BESSEL = true>
 VMF_HD T kl_value(T kappa, int variant, const KlBessel& kb, T* grad) {
   T g = 0, kl = 0;
+  if (!BESSEL && (variant == VMF_KL_S1_I0I1 || variant == VMF_KL_STABLE_M2)) {
+    *grad = (T)NAN;
+    return (T)NAN;
+  }
   switch (variant) {
     case VMF_KL_SPHERICAL_PIECEWISE: {  // model/spherical_vae.py:141-184
       const T eps = (T)1e-8;
@@ -121,7 +129,7 @@ VMF_HD T kl_value(T kappa, int variant, const KlBessel& kb, T* grad) {
       kl = M<T>::log(kappa) - M<T>::log(S) + kappa * (C / S) - (T)1.0;
       g = (T)1 / kappa + kappa * (sh * S - C * C) / (S * S);
     } break;
-    case VMF_KL_S1_I0I1: {  // regular_cnn/s1_vae.py:83-88: unscaled I0, I1 overflow where exp does
+    case VMF_KL_S1_I0I1: if constexpr (BESSEL) {  // regular_cnn/s1_vae.py:83-88: unscaled I0, I1 overflow where exp does
       T ex = M<T>::exp(M<T>::abs(kappa));
       T i0 = (T)ive_eval(kb.o0, (double)kappa) * ex;
       T i1 = (T)ive_eval(kb.o1, (double)kappa) * ex;
@@ -144,7 +152,7 @@ VMF_HD T kl_value(T kappa, int variant, const KlBessel& kb, T* grad) {
         g = (T)1 / k - k * csch2;
       }
     } break;
-    case VMF_KL_STABLE_M2: {
+    case VMF_KL_STABLE_M2: if constexpr (BESSEL) {
       double k = (double)kappa;
       double e0 = ive_eval(kb.o0, k), e1 = ive_eval(kb.o1, k);
       double A = e1 / e0;
@@ -182,9 +190,13 @@ VMF_HD void fast_sinh_cosh(float k, float* sh, float* ch) {
   }
 }
 
-VMF_HD float cheb_sum_f32(const float* c, int n, float t) {
+// Unrolled on purpose (unlike the double-precision sums): single-precision coefficients are free 32-bit literals of
+// the fma, so a term costs two instructions instead of a scalar load and the loop bookkeeping.
+template <int n>
+VMF_HD float cheb_sum_f32(const float (&c)[n], float t) {
   float b0 = 0.0f, b1 = 0.0f;
   const float t2 = 2.0f * t;
+#pragma unroll
   for (int k = n - 1; k >= 1; --k) {
     const float b = ::fmaf(t2, b0, c[k]) - b1;
     b1 = b0;
@@ -264,15 +276,15 @@ VMF_HD bool kl_value_fast(float kappa, int variant, float* kl_out, float* grad) 
       float e0, A, omA;
       if (a <= 8.0f) {
         const float t = 0.25f * a - 1.0f;
-        e0 = cheb_sum_f32(I0E_A_F32, I0E_A_F32_N, t);
-        omA = cheb_sum_f32(I01R_A_F32, I01R_A_F32_N, t);
+        e0 = cheb_sum_f32(I0E_A_F32, t);
+        omA = cheb_sum_f32(I01R_A_F32, t);
         A = 1.0f - omA;
       } else {
         const float ra = fast_rcp(a);
         const float t = 16.0f * ra - 1.0f;
-        const float B0 = cheb_sum_f32(I0E_B_F32, I0E_B_F32_N, t);
+        const float B0 = cheb_sum_f32(I0E_B_F32, t);
         e0 = B0 * ::sqrtf(ra);
-        omA = cheb_sum_f32(I01D_B_F32, I01D_B_F32_N, t) * ra * fast_rcp(B0);
+        omA = cheb_sum_f32(I01D_B_F32, t) * ra * fast_rcp(B0);
         A = 1.0f - omA;
       }
       const float i0 = e0 * fast_exp(a);
@@ -305,15 +317,22 @@ VMF_HD bool kl_value_fast(float kappa, int variant, float* kl_out, float* grad) 
 }
 
 // value + derivative for the kernels: the fast form for fp32 where there is one, the accurate form otherwise
-template <typename T>
+template <typename T, bool BESSEL = true>
 VMF_HD T kl_eval(T kappa, int variant, const KlBessel& kb, T* grad) {
-  return kl_value<T>(kappa, variant, kb, grad);
+  return kl_value<T, true>(kappa, variant, kb, grad);
 }
 template <>
-VMF_HD float kl_eval<float>(float kappa, int variant, const KlBessel& kb, float* grad) {
+VMF_HD float kl_eval<float, true>(float kappa, int variant, const KlBessel& kb, float* grad) {
   float kl;
   if (kl_value_fast(kappa, variant, &kl, grad)) return kl;
-  return kl_value<float>(kappa, variant, kb, grad);
+  return kl_value<float, true>(kappa, variant, kb, grad);
+}
+// fp32 tensors, every variant but the stable m = 2 form (the launch code picks the instantiation)
+template <>
+VMF_HD float kl_eval<float, false>(float kappa, int variant, const KlBessel& kb, float* grad) {
+  float kl;
+  if (kl_value_fast(kappa, variant, &kl, grad)) return kl;
+  return kl_value<float, false>(kappa, variant, kb, grad);
 }
 
 // ---- general-m pieces ---------------------------------------------------------------------------

@@ -16,8 +16,12 @@ SO = os.path.join(HERE, "hostcheck", "libvmf_hostcheck.so")
 
 @pytest.fixture(scope="module")
 def hc():
-    if not os.path.exists(SO):
-        hipcc = "/opt/rocm/bin/hipcc"
+    hipcc = "/opt/rocm/bin/hipcc"
+    csrc = os.path.join(os.path.dirname(HERE), "medicalimageanalysis_amd", "csrc")
+    deps = [os.path.join(HERE, "hostcheck", "hostcheck.hip")] + [os.path.join(csrc, f) for f in os.listdir(csrc)
+                                                                 if f.endswith(".h")]
+    stale = os.path.exists(SO) and any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps)
+    if not os.path.exists(SO) or (stale and os.path.exists(hipcc)):
         if not os.path.exists(hipcc):
             pytest.skip("hipcc not available and hostcheck library not prebuilt")
         subprocess.check_call([hipcc, "-O2", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-shared", "-o", SO,
