@@ -160,16 +160,10 @@ extern "C" int vmf_elbo_fwd(const void* x, const void* x_hat, const void* kappa,
   if (work < n_kappa) work = n_kappa;
   const int grid = vmf_grid_for(work, 256, VMF_ELBO_WORKSPACE_DOUBLES / 2);
   if (vec) {
-    // fp32 and not the stable m = 2 form: the instantiation without the double-precision Bessel code (a third of the
-    // registers)
-    if (variant == VMF_KL_STABLE_M2)
-      hipLaunchKernelGGL((elbo_fwd_kernel<float, 4, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                         (const float*)x, (const float*)x_hat, (const float*)kappa, workspace, n_x, n_hat, n_kappa,
-                         variant, kb);
-    else
-      hipLaunchKernelGGL((elbo_fwd_kernel<float, 4, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                         (const float*)x, (const float*)x_hat, (const float*)kappa, workspace, n_x, n_hat, n_kappa,
-                         variant, kb);
+    // fp32: the instantiation without the double-precision Bessel code (a third of the registers)
+    hipLaunchKernelGGL((elbo_fwd_kernel<float, 4, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)x, (const float*)x_hat, (const float*)kappa, workspace, n_x, n_hat, n_kappa,
+                       variant, kb);
   } else {
     VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((elbo_fwd_kernel<T, 1, true>), dim3(grid), dim3(256), 0,
                                                  (hipStream_t)stream, (const T*)x, (const T*)x_hat,
@@ -199,14 +193,9 @@ extern "C" int vmf_elbo_bwd(const void* x, const void* x_hat, const void* kappa,
   if (d_kappa && work < n_kappa) work = n_kappa;
   const int grid = vmf_grid_for(work, 256);
   if (vec) {
-    if (variant == VMF_KL_STABLE_M2)
-      hipLaunchKernelGGL((elbo_bwd_kernel<float, 4, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                         (const float*)x, (const float*)x_hat, (const float*)kappa, (const float*)grad_loss, (float)a_rec,
-                         (float)a_kl, (float*)d_x_hat, (float*)d_kappa, n_x, n_hat, n_kappa, variant, kb);
-    else
-      hipLaunchKernelGGL((elbo_bwd_kernel<float, 4, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                         (const float*)x, (const float*)x_hat, (const float*)kappa, (const float*)grad_loss, (float)a_rec,
-                         (float)a_kl, (float*)d_x_hat, (float*)d_kappa, n_x, n_hat, n_kappa, variant, kb);
+    hipLaunchKernelGGL((elbo_bwd_kernel<float, 4, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)x, (const float*)x_hat, (const float*)kappa, (const float*)grad_loss, (float)a_rec,
+                       (float)a_kl, (float*)d_x_hat, (float*)d_kappa, n_x, n_hat, n_kappa, variant, kb);
   } else {
     VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((elbo_bwd_kernel<T, 1, true>), dim3(grid), dim3(256), 0,
                                                  (hipStream_t)stream, (const T*)x, (const T*)x_hat,

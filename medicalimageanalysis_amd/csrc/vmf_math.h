@@ -90,8 +90,7 @@ static inline KlBessel make_kl_bessel() {
 
 // BESSEL = false leaves the two forms that need the double-precision Bessel code out (they return NaN): the fp32
 // kernels use it as the per-element fall-back of the fast forms below, where those two variants only fall back for a
-// NaN kappa (S^1) or are not dispatched at all (stable m = 2) -- and without the Bessel code the kernels need a third
-// of the registers.
+// NaN kappa -- and without the Bessel code the kernels need a third of the registers.
 template <typename T, bool BESSEL = true>
 VMF_HD T kl_value(T kappa, int variant, const KlBessel& kb, T* grad) {
   T g = 0, kl = 0;
@@ -170,7 +169,7 @@ VMF_HD T kl_value(T kappa, int variant, const KlBessel& kb, T* grad) {
 // The accurate version above spends ~500 instructions per element in libm's sinh / cosh / log / exp (and, for the
 // S^1 form, two double Chebyshev sums); the streams over kappa then run at a few percent of the memory rate.  For
 // fp32 tensors the contract is 1e-4 relative, which the hardware exp2 / log2 and single-precision series meet with
-// two orders of magnitude to spare.  The stable m = 2 form keeps the double path (k A - k cancels for large k).
+// two orders of magnitude to spare.
 // (fast_exp2 / fast_log2 / fast_exp / fast_rcp / fast_log live in common.h)
 
 // sinh and cosh of k >= 0 with sinhf's overflow point (k > 89.416): Taylor below 1 (no cancellation), the two
@@ -237,8 +236,7 @@ VMF_HD void kl_m3_eps_fast(float k, float eps, float* kl, float* g) {
 }
 
 // Same values and NaN / inf behaviour as kl_value<float> (to the tolerance above); returns false when there is no
-// fast form (the stable m = 2 variant; non-positive or NaN kappa in the unguarded variants, which are the accurate
-// form's business).
+// fast form (non-positive or NaN kappa in the unguarded variants, which are the accurate form's business).
 VMF_HD bool kl_value_fast(float kappa, int variant, float* kl_out, float* grad) {
   float kl = 0.0f, g = 0.0f;
   switch (variant) {
@@ -302,11 +300,39 @@ VMF_HD bool kl_value_fast(float kappa, int variant, float* kl_out, float* grad) 
         const float e2 = fast_exp(-2.0f * k);
         const float om = 1.0f - e2;
         const float rom = fast_rcp(om);
-        const float coth = (1.0f + e2) * rom;
-        const float log_sinh = k + fast_log(om) - 0.69314718055994530942f;
-        kl = fast_log(k) - log_sinh + k * coth - 1.0f;
+        // log k - log sinh k + k coth k - 1 with the two O(k) terms cancelled by hand: k coth k - k = 2 k e2 / (1 - e2)
+        kl = fast_log(k) - fast_log(om) + (0.69314718055994530942f - 1.0f) + 2.0f * k * e2 * rom;
         g = fast_rcp(k) - k * (4.0f * e2 * rom * rom);
       }
+    } break;
+    case VMF_KL_STABLE_M2: {
+      // k I1/I0 - log I0 without the exponential: with e0 = I0 e^-k and 1 - A from its own series (as above),
+      // k A - log I0 = -k (1 - A) - log e0, finite for every k.  Below 1/4 the O(k) terms of that form cancel, and the
+      // series k^2/4 - 3 k^4/64 + 5 k^6/576 - 77 k^8/49152 is exact to 2e-9 relative.
+      if (kappa != kappa) return false;
+      const float a = ::fabsf(kappa);
+      if (a < 0.25f) {
+        const float k2 = a * a;
+        kl = k2 * (0.25f + k2 * (-3.0f / 64.0f + k2 * (5.0f / 576.0f + k2 * (-77.0f / 49152.0f))));
+        g = a * (0.5f + k2 * (-3.0f / 16.0f + k2 * (5.0f / 96.0f + k2 * (-77.0f / 6144.0f))));
+      } else {
+        float e0, omA;
+        if (a <= 8.0f) {
+          const float t = 0.25f * a - 1.0f;
+          e0 = cheb_sum_f32(I0E_A_F32, t);
+          omA = cheb_sum_f32(I01R_A_F32, t);
+        } else {
+          const float ra = fast_rcp(a);
+          const float t = 16.0f * ra - 1.0f;
+          const float B0 = cheb_sum_f32(I0E_B_F32, t);
+          e0 = B0 * ::sqrtf(ra);
+          omA = cheb_sum_f32(I01D_B_F32, t) * ra * fast_rcp(B0);
+        }
+        const float A = 1.0f - omA;
+        kl = -a * omA - fast_log(e0);
+        g = a * omA * (1.0f + A) - A;
+      }
+      if (kappa < 0.0f) g = -g;
     } break;
     default:
       return false;
@@ -327,7 +353,7 @@ VMF_HD float kl_eval<float, true>(float kappa, int variant, const KlBessel& kb, 
   if (kl_value_fast(kappa, variant, &kl, grad)) return kl;
   return kl_value<float, true>(kappa, variant, kb, grad);
 }
-// fp32 tensors, every variant but the stable m = 2 form (the launch code picks the instantiation)
+// fp32 tensors with 128-bit accesses (the launch code picks the instantiation)
 template <>
 VMF_HD float kl_eval<float, false>(float kappa, int variant, const KlBessel& kb, float* grad) {
   float kl;

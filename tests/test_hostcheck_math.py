@@ -140,12 +140,27 @@ def test_device_fast_fp32_kl_matches_reference(hc, golden, oracle, name, variant
     _close_grad(d2, g64, kk, rtol=1e-4)
 
 
-def test_fast_kl_has_no_form_for_stable_m2(hc):
-    k = np.ones(4, np.float32)
-    out, dout = np.empty_like(k), np.empty_like(k)
-    assert hc.hc_kl_fast_f32(_p(k), _p(out), _p(dout), C.c_int64(4), 5) == 0
-    assert hc.hc_kl_fast_f32(_p(k), _p(out), _p(dout), C.c_int64(4), 4) == 1
-    np.testing.assert_allclose(out, np.log(1.0) - np.log(np.sinh(1.0)) + 1 / np.tanh(1.0) - 1.0, rtol=1e-6)
+@pytest.mark.parametrize("variant", [4, 5])
+def test_fast_fp32_kl_stable_forms_match_oracle(hc, oracle, variant):
+    """the overflow-free variants (m = 3 and m = 2; not in the reference, so the oracle in double is the yardstick):
+    dense grid from 1e-3 to 1e4, including the switch points of the fast forms (1/4, 1, 8); negative kappa mirrors"""
+    kk = np.exp(np.linspace(np.log(1e-3), np.log(1e4), 6001)).astype(np.float32)
+    kk = np.concatenate([kk, np.float32([0.25, 1.0, 8.0, 0.2499999, 8.000001])])
+    o, d = np.empty_like(kk), np.empty_like(kk)
+    assert hc.hc_kl_fast_f32(_p(kk), _p(o), _p(d), C.c_int64(kk.size), variant) == 1
+    r64, g64, _ = oracle.vmf_kl(kk.astype(np.float64), variant)
+    np.testing.assert_allclose(o, r64, rtol=2e-5, atol=1e-9)
+    _close_grad(d, g64, kk, rtol=1e-4)
+    if variant == 5:  # even in kappa, odd derivative
+        o2, d2 = np.empty_like(kk), np.empty_like(kk)
+        neg = np.ascontiguousarray(-kk)
+        assert hc.hc_kl_fast_f32(_p(neg), _p(o2), _p(d2), C.c_int64(kk.size), variant) == 1
+        np.testing.assert_array_equal(o2, o)
+        np.testing.assert_array_equal(d2, -d)
+    nan = np.float32([np.nan])  # NaN stays NaN, through the fast form or by handing over to the accurate one
+    o1, d1 = np.zeros(1, np.float32), np.zeros(1, np.float32)
+    handled = hc.hc_kl_fast_f32(_p(nan), _p(o1), _p(d1), C.c_int64(1), variant)
+    assert handled == 0 or (np.isnan(o1[0]) and np.isnan(d1[0]))
 
 
 def test_device_rsample_rows_match_reference(hc, golden):
