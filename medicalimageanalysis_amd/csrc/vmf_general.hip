@@ -28,8 +28,9 @@
 constexpr int WAVES = VMF_WAVES;
 // Rows per tile.  The rejection phase ends with a tail in which the last few rows of the tile wait for their
 // acceptance on a mostly idle wave; its cost is per tile, so narrow rows, whose phase 2 is short, take larger tiles:
-// 384 rows for m <= 4 (one lane per row) and 320 for m <= 16.  Measured on 2^27 / 2^24 rows against 128-row tiles:
-// m = 2 1.66 -> 1.22 ms, m = 3 0.259 -> 0.211, m = 4 0.220 -> 0.179, m = 8 .. 16 -4 .. -10 %.  512-row tiles are
+// 384 rows for m <= 4 (one lane per row) and 320 for m <= 16; the circle instantiation, with a single slab, 1024
+// (2^27 rows: 0.90 ms with 512-row tiles, 0.82 with 1024, 1.06 with 2048).  Measured on 2^27 / 2^24 rows against
+// 128-row tiles: m = 2 1.66 -> 1.22 ms, m = 3 0.259 -> 0.211, m = 4 0.220 -> 0.179, m = 8 .. 16 -4 .. -10 %.  512-row tiles are
 // slower again (the LDS slabs then limit the resident waves), and walking several 128-row tiles per wave was 10-20 %
 // slower than one (more waves in flight beat fewer wave launches).
 #ifndef VMF_TILE_ROWS_LPR1
@@ -39,7 +40,7 @@ constexpr int WAVES = VMF_WAVES;
 #define VMF_TILE_ROWS_NARROW 320
 #endif
 #ifndef VMF_TILE_ROWS_CIRCLE
-#define VMF_TILE_ROWS_CIRCLE 512
+#define VMF_TILE_ROWS_CIRCLE 1024
 #endif
 constexpr int tile_rows(int lpr) { return lpr == 1 ? VMF_TILE_ROWS_LPR1 : (lpr <= 4 ? VMF_TILE_ROWS_NARROW : VMF_TILE_ROWS); }
 constexpr uint32_t SLOT_GAUSS = 0x10000u;
@@ -161,8 +162,10 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
   __shared__ T s_w[WAVES][CIRCLE ? 1 : TILE_ROWS];
   __shared__ T s_omw[WAVES][TILE_ROWS];
   // fp32 fused log_prob: log C_m(kappa) and kappa of the tile's rows (kappa is read from HBM once per row)
-  __shared__ float s_lc[sizeof(T) == 4 ? WAVES : 1][sizeof(T) == 4 ? TILE_ROWS : 1];
-  __shared__ float s_kp[sizeof(T) == 4 ? WAVES : 1][sizeof(T) == 4 ? TILE_ROWS : 1];
+  // (not for the circle: one lane owns a row there, so log p is formed and stored in phase 2 directly)
+  constexpr bool LP_SLAB = sizeof(T) == 4 && !CIRCLE;
+  __shared__ float s_lc[LP_SLAB ? WAVES : 1][LP_SLAB ? TILE_ROWS : 1];
+  __shared__ float s_kp[LP_SLAB ? WAVES : 1][LP_SLAB ? TILE_ROWS : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int RPI = 64 / LPR;  // rows per wave step
   const int sub = lane % LPR, grp = lane / LPR;
@@ -176,8 +179,8 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
   const bool circle = CIRCLE || (LPR == 1 && MODE == 0 && m == 2 && !pre && p.gauss == nullptr);
   T* const sw = s_w[wave];
   T* const somw = s_omw[wave];
-  float* const slc = s_lc[sizeof(T) == 4 ? wave : 0];
-  float* const skp = s_kp[sizeof(T) == 4 ? wave : 0];
+  float* const slc = s_lc[LP_SLAB ? wave : 0];
+  float* const skp = s_kp[LP_SLAB ? wave : 0];
 
   {
     const uint32_t bid = xcd_block(blockIdx.x, gridDim.x);
@@ -192,7 +195,7 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
     //      the next unassigned row of the tile (ballot + prefix popcount) ----
     // fp32 fused log_prob: log C_m(kappa) of the tile's rows, evaluated in single precision here (two rows per lane)
     // so that phase 2 writes log p once; fp64 outputs get theirs from the double-precision pre-pass kernel instead
-    const bool lp32 = sizeof(T) == 4 && p.logp != nullptr;
+    const bool lp32 = LP_SLAB && p.logp != nullptr;
     if (lp32 || !pre) {
       for (int i = lane; i < ntile; i += 64) {
         const T kap = kap_t[i * p.kappa_stride];
@@ -344,7 +347,8 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
       mu0 *= inv;
       gm *= inv;
       const T d0 = (T)1 - mu0;
-      dd = d0 * d0 + dd * (inv * inv);  // |e1 - mu|^2
+      const T tail = dd * (inv * inv);  // |mu|^2 without its first element
+      dd = d0 * d0 + tail;              // |e1 - mu|^2
       const T omw = (LPR == 1 && circle) ? M<T>::abs(somw[rr]) : somw[rr];
       const T w = CIRCLE ? (T)1 - omw : sw[rr];
       T c2 = omw * ((T)1 + w);
@@ -390,15 +394,23 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
           }
         }
         if (p.logp && sub == 0) {
-          const T mm = dd - (T)1 + (T)2 * mu0;                // |mu|^2
-          const T mz = w * mu0 + f * gm - coef * (mu0 - mm);  // <mu, z>
-          if (sizeof(T) == 4) slc[rr] += skp[rr] * (float)mz;  // written out coalesced once the tile is done
-          else p.logp[tile0 + rr] += kap_t[rr * p.kappa_stride] * mz;  // log C_m(kappa) came from the pre-pass
+          // <mu, z> = <mu, z'> - coef <mu, d> with <mu, d> = mu0 - |mu|^2 = mu0 (1 - mu0) - tail: written through the
+          // two small quantities, because coef ~ 1 / |d|^2 multiplies it and mu0 - |mu|^2 formed from rounded values
+          // near 1 loses everything when mu is close to the pole (a circle's mu is, for one row in a few hundred)
+          const T mz = w * mu0 + f * gm - coef * (mu0 * d0 - tail);
+          if (LP_SLAB) {
+            slc[rr] += skp[rr] * (float)mz;  // written out coalesced once the tile is done
+          } else if (sizeof(T) == 4) {       // circle: consecutive lanes hold consecutive rows
+            const float kap = (float)kap_t[rr * p.kappa_stride];
+            p.logp[tile0 + rr] = (T)(vmf_log_norm_f32v(p.lc_v, p.lc_lg, p.lc_c0, kap) + kap * (float)mz);
+          } else {
+            p.logp[tile0 + rr] += kap_t[rr * p.kappa_stride] * mz;  // log C_m(kappa) came from the pre-pass
+          }
         }
       }
     }
     wave_lds_sync();
-    if (sizeof(T) == 4 && p.logp)
+    if (LP_SLAB && p.logp)
       for (int i = lane; i < ntile; i += 64) p.logp[tile0 + i] = (T)slc[i];
   }
 }

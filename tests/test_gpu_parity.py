@@ -1033,6 +1033,19 @@ def test_general_fused_log_prob_matches_separate_call():
     np.testing.assert_allclose(N(lp), N(q.log_prob(z)), rtol=1e-9, atol=1e-8)
     z5 = q.rsample(torch.Size([2]))
     assert z5.shape == (2, n, m)
+    # every instantiation of the fused form (the circle writes log p from phase 2, the others through the LDS slab;
+    # fp64 through the pre-pass): against the separate call evaluated in double
+    for m2, n2 in ((2, 5000), (3, 2000), (10, 2000), (16, 2000), (130, 500), (512, 300)):
+        for dt, tol in ((torch.float32, 2e-4), (torch.float64, 1e-9)):
+            mu2 = torch.nn.functional.normalize(torch.randn(n2, m2, device=DEV, dtype=torch.float64), dim=-1).to(dt)
+            k2 = torch.exp(torch.rand(n2, device=DEV, dtype=torch.float64) * np.log(1e3)).to(dt)
+            z2, lp2 = VonMisesFisher(mu2, k2, validate_args=False).rsample(return_log_prob=True)
+            want = VonMisesFisher(mu2.double(), k2.double(), validate_args=False).log_prob(z2.double())
+            # fp32: z itself is rounded to 6e-8 per component, which moves kappa <mu, z> by ~kappa 1e-7 whatever
+            # evaluates it (log C_m ~ -kappa cancels most of kappa <mu, z>, so |log p| does not cover that)
+            slack = 5e-7 * k2.double() if dt == torch.float32 else 0.0
+            err = (((lp2.double() - want).abs() - slack).clamp(min=0) / (want.abs() + 1.0)).max()
+            assert float(err) < tol, (m2, dt, float(err))
 
 
 # ---- models against the reference's own forward / loss / gradients ----------------------------------------------------
