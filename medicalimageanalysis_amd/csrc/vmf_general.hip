@@ -156,7 +156,7 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
   constexpr bool FAST = MODE == 2;
   constexpr bool CIRCLE = MODE == 3;
   const PhiloxKey key = philox_resolve(p.ka);  // scalar: seed + host offset (+ device-resident offset)
-  // the circle instantiation parks only 1 - w (w = 1 - (1 - w) exactly as the proposal formed it), so its tiles can be
+  // the circle instantiation parks one word per row (see circle_pack), so its tiles can be
   // larger in the same LDS footprint
   constexpr int TILE_ROWS = CIRCLE ? VMF_TILE_ROWS_CIRCLE : tile_rows(LPR);
   __shared__ T s_w[WAVES][CIRCLE ? 1 : TILE_ROWS];
@@ -174,7 +174,7 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
   // Circle (m = 2) with counter noise: a proposal needs two uniforms (the Beta(1/2,1/2) angle and the accept draw)
   // and the tangent "direction" is one sign, so one Philox call serves two proposals (words x,y then z,w of call
   // k >> 1) and bit 0 of the first call's word x (below the 23 bits u01 uses) is the sign.  The sign travels to
-  // phase 2 in the sign bit of the parked 1 - w (which is never negative).
+  // phase 2 in the sign bit of the parked word (see circle_pack).
   // MODE 3 is this case with m a compile-time 2 and 64-bit accesses; MODE 0 takes it when rows are not 8-byte aligned.
   const bool circle = CIRCLE || (LPR == 1 && MODE == 0 && m == 2 && !pre && p.gauss == nullptr);
   T* const sw = s_w[wave];
@@ -220,7 +220,7 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
       while (__ballot(active) != 0ull) {
         bool acc = false;
         if (active) {
-          T w, omw;
+          T w = 0, omw = 0, pc = 0, ps = 0;  // circle: cos^2 / den and sin^2 / den of the proposal kept
           if (pre) {
             const int64_t row = tile0 + my;
             acc = wood_try<T>(a, b, d, m, p.prop_e[row * p.max_prop + k], p.prop_u[row * p.max_prop + k], &w, &omw);
@@ -230,20 +230,26 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
             // of a wave sit at different k, so skipping the call on odd k would not shorten the wave's iteration)
             const U4 rc = philox4x32_10(grow0 + (uint64_t)my, (uint32_t)(k >> 1), key);
             if (k == 0) neg = (rc.x & 1u) != 0u;
-            T w1, omw1;
-            const bool a0 = wood_try_counter<T>(b, 2, (T)0.5, u01<T>(rc.x), u01<T>(rc.y), &w, &omw);
-            const bool a1 = wood_try_counter<T>(b, 2, (T)0.5, u01<T>(rc.z), u01<T>(rc.w), &w1, &omw1);
+            T pc1, ps1;
+            const bool a0 = wood_try_circle<T>(b, u01<T>(rc.x), u01<T>(rc.y), &pc, &ps);
+            const bool a1 = wood_try_circle<T>(b, u01<T>(rc.z), u01<T>(rc.w), &pc1, &ps1);
             const bool use0 = a0 || k + 1 >= p.max_prop;
             acc = use0 || a1;
-            if (!use0) { w = w1; omw = omw1; ++k; }
+            if (!use0) { pc = pc1; ps = ps1; ++k; }
           } else {
             const U4 r = philox4x32_10(grow0 + (uint64_t)my, (uint32_t)k, key);
             acc = wood_try_counter<T>(b, m, u01<T>(r.x), u01<T>(r.y), u01<T>(r.z), &w, &omw);
           }
           if (k + 1 >= p.max_prop) acc = true;  // the last proposal allowed is taken regardless
           if (acc) {
+            T parked = omw;
+            if (LPR == 1 && circle) {
+              parked = circle_pack((T)2 * b * pc, (T)2 * ps, neg);
+              T opw;
+              circle_unpack(parked, &w, &omw, &opw);  // w and 1 - w as phase 2 will see them
+            }
             if (!CIRCLE) sw[my] = w;
-            somw[my] = (LPR == 1 && circle && neg) ? -omw : omw;
+            somw[my] = parked;
             if (p.w_out) p.w_out[tile0 + my] = w;
             if (p.omw_out) p.omw_out[tile0 + my] = omw;
             if (p.accept_idx) p.accept_idx[tile0 + my] = k;
@@ -349,9 +355,15 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
       const T d0 = (T)1 - mu0;
       const T tail = dd * (inv * inv);  // |mu|^2 without its first element
       dd = d0 * d0 + tail;              // |e1 - mu|^2
-      const T omw = (LPR == 1 && circle) ? M<T>::abs(somw[rr]) : somw[rr];
-      const T w = CIRCLE ? (T)1 - omw : sw[rr];
-      T c2 = omw * ((T)1 + w);
+      T w, omw, opw;  // w, 1 - w, 1 + w
+      if (LPR == 1 && circle) {
+        circle_unpack(somw[rr], &w, &omw, &opw);
+      } else {
+        omw = somw[rr];
+        w = sw[rr];
+        opw = (T)1 + w;
+      }
+      T c2 = omw * opw;
       c2 = c2 < (T)1e-10 ? (T)1e-10 : c2;
       const T f = F<T>::sqrt(c2) * F<T>::rsqrt(gg);
       const T zd = w * d0 - f * gm;

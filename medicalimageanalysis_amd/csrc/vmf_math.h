@@ -394,12 +394,63 @@ __device__ __forceinline__ bool wood_try_counter(T b, int m, T U, T V, T uacc, T
   T sq = (T)1;
   if (m > 2) sq = F<T>::one_minus_exp2((T)2 / (T)(m - 2) * F<T>::log2(U));  // 1 - U^(2/(m-2))
   const T c = F<T>::sqrt(sq) * F<T>::cos2pi(V);
-  const T den = (T)1 - (T)0.5 * ((T)1 - b) * ((T)1 + c);
+  const T opc = (T)1 + c;
+  const T den = (T)1 - (T)0.5 * ((T)1 - b) * opc;
   const T rden = F<T>::rcp(den);
-  *omw = b * ((T)1 + c) * rden;
+  *omw = b * opc * rden;
   *w = (T)1 - *omw;
   const T s = (T)0.5 * ((T)1 - b) * c * rden;
   return (T)(m - 1) * F<T>::log1p_minus_over_ln2(s) >= F<T>::log2(uacc);  // both sides divided by ln 2
+}
+
+// Circle (m = 2): the proposal cosine c = cos 2 pi V follows the arcsine law, half its mass near -1 and +1, where
+// 1 + c, 1 - c and the denominator cancel in turn.  The half angle gives every factor without cancellation:
+//   1 + c = 2 cos^2(pi V),  1 - c = 2 sin^2(pi V),  den = 1 - (1-b)(1+c)/2 = b cos^2 + sin^2,
+//   1 - w = 2 b cos^2 / den,  1 + w = 2 sin^2 / den
+// and both 1 - w and 1 + w are carried to the composition (an accepted w within 1e-6 of -1 is rare but happens at kappa ~ 1, and
+// 1 + w formed from the rounded w loses its digits there: 1e-4 in z).
+template <typename T>
+__device__ __forceinline__ bool wood_try_circle(T b, T V, T uacc, T* pc, T* ps) {
+  // returns cos^2 / den and sin^2 / den; the caller forms 1 - w = 2 b pc and 1 + w = 2 ps for the proposal it keeps
+  T sh, ch;
+  F<T>::sincos2pi((T)0.5 * V, &sh, &ch);
+  const T ch2 = ch * ch, sh2 = sh * sh;
+  const T rden = F<T>::rcp(b * ch2 + sh2);
+  *pc = ch2 * rden;
+  *ps = sh2 * rden;
+  const T s = ((T)0.5 - (T)0.5 * b) * (*pc - *ps);  // (1-b) c / (2 den)
+  // m - 1 = 1, so log(1+s) - s >= ln u can be tested as 1 + s >= u e^s: one exponential instead of two logarithms
+  return (T)1 + s >= uacc * F<T>::exp2((T)1.44269504088896340736 * s);
+}
+// One LDS word per accepted circle row: the smaller of 1 - w and 1 + w (so that the other one, 2 minus it, is exact to
+// an ulp of 2 and w = +-(1 - it) keeps its digits at both ends), which of the two in the mantissa's last bit, and the
+// tangent's sign in the sign bit.
+__device__ __forceinline__ float circle_pack(float omw, float opw, bool neg) {
+  const bool hi = omw > 1.0f;
+  const uint32_t bits = (__float_as_uint(hi ? opw : omw) & 0x7ffffffeu) | (hi ? 1u : 0u) | (neg ? 0x80000000u : 0u);
+  return __uint_as_float(bits);
+}
+__device__ __forceinline__ double circle_pack(double omw, double opw, bool neg) {
+  const bool hi = omw > 1.0;
+  const unsigned long long bits = ((unsigned long long)__double_as_longlong(hi ? opw : omw) & 0x7ffffffffffffffeull) |
+                                  (hi ? 1ull : 0ull) | (neg ? 0x8000000000000000ull : 0ull);
+  return __longlong_as_double((long long)bits);
+}
+__device__ __forceinline__ void circle_unpack(float x, float* w, float* omw, float* opw) {
+  const uint32_t bits = __float_as_uint(x);
+  const float v = __uint_as_float(bits & 0x7ffffffeu);
+  const bool hi = (bits & 1u) != 0u;
+  *omw = hi ? 2.0f - v : v;
+  *opw = hi ? v : 2.0f - v;
+  *w = hi ? v - 1.0f : 1.0f - v;
+}
+__device__ __forceinline__ void circle_unpack(double x, double* w, double* omw, double* opw) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+  const double v = __longlong_as_double((long long)(bits & 0x7ffffffffffffffeull));
+  const bool hi = (bits & 1ull) != 0ull;
+  *omw = hi ? 2.0 - v : v;
+  *opw = hi ? v : 2.0 - v;
+  *w = hi ? v - 1.0 : 1.0 - v;
 }
 
 // b(kappa) alone (what the counter-based path needs)
