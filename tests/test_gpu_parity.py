@@ -952,6 +952,45 @@ def test_general_backward_vs_autograd_of_restated_forward(m):
     assert torch.isfinite(mu.grad).all() and torch.isfinite(kappa.grad).all()
 
 
+@pytest.mark.parametrize("m", [2, 3, 10, 64, 512])
+def test_general_fp32_draws_and_gradients_agree_with_fp64(m):
+    """the same rows, the same counters, once in fp32 and once in fp64 (inputs rounded to fp32 first): where both accept
+    the same proposal the samples agree to 2e-5 (the fp32 contract is 1e-4) and the backward pass -- hardware
+    reciprocals and square roots in fp32 -- to 2e-3 of each row's gradient.  Guards the cancellation-prone spots:
+    w near +-1 on the circle, mu near the pole."""
+    lib, sp = _lib.lib(), _lib.stream_ptr(DEV)
+    g = torch.Generator(device=DEV).manual_seed(60 + m)
+    n = 20000
+    mu = torch.nn.functional.normalize(torch.randn(n, m, device=DEV, dtype=torch.float64, generator=g), dim=-1).float()
+    kappa = torch.exp(torch.rand(n, device=DEV, dtype=torch.float64, generator=g) * np.log(1e3)).float()
+    gz = torch.randn(n, m, device=DEV, generator=g)
+
+    def run(dt):
+        a, k, c = mu.to(dt).contiguous(), kappa.to(dt).contiguous(), gz.to(dt).contiguous()
+        z, w, omw = torch.empty_like(a), torch.empty_like(k), torch.empty_like(k)
+        idx = torch.empty(n, device=DEV, dtype=torch.int32)
+        code = _lib.dtype_code(a)
+        _lib.check(lib.vmf_rsample_fwd(_lib.ptr(a), m, _lib.ptr(k), 1, _lib.ptr(z), _lib.ptr(w), _lib.ptr(omw),
+                                       C.c_void_p(idx.data_ptr()), None, n, m, None, None, 0, None, 64, 0, 5, 9, None, 0,
+                                       code, sp), "vmf_rsample_fwd")
+        dmu, dk = torch.empty_like(a), torch.empty_like(k)
+        _lib.check(lib.vmf_rsample_bwd(_lib.ptr(a), m, _lib.ptr(k), 1, _lib.ptr(w), _lib.ptr(omw), _lib.ptr(c), None,
+                                       _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 5, 9, None, 0, code, sp), "vmf_rsample_bwd")
+        return z.double(), idx, dmu.double(), dk.double()
+
+    z32, i32, dm32, dk32 = run(torch.float32)
+    z64, i64, dm64, dk64 = run(torch.float64)
+    same = i32 == i64
+    assert float(same.float().mean()) > 0.999
+    assert float((z32 - z64).abs().amax(dim=1)[same].max()) < 2e-5
+    row = dm64.abs().amax(dim=1)
+    floor = 1e-3 * float(row.median())
+    err_mu = (dm32 - dm64).abs().amax(dim=1) / (row + floor)
+    assert float(err_mu[same].max()) < 2e-3, float(err_mu[same].max())
+    err_k = (dk32 - dk64).abs() / (dk64.abs() + 0.05 * dk64.abs().median())
+    assert float((err_k[same] < 5e-3).float().mean()) > 0.999, float((err_k[same] < 5e-3).float().mean())
+
+
 @pytest.mark.parametrize("tag", ["f64", "f32"])
 @pytest.mark.parametrize("m", [2, 3, 10, 64, 512])
 def test_general_log_prob_entropy_kl(oracle, tag, m):
