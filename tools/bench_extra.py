@@ -82,6 +82,21 @@ def main():
         del mu, z
         torch.cuda.empty_cache()
 
+    # --- shared-parameter layout: one (mu, kappa), sample_shape = (N,): only z moves (m * 4 bytes per draw)
+    for m, n in ((64, 1 << 24), (512, 1 << 22)):
+        mu1 = torch.nn.functional.normalize(torch.randn(1, m, device=DEV, generator=g), dim=-1)
+        k1 = torch.tensor([50.0], device=DEV)
+        z = torch.empty(n, m, device=DEV)
+
+        def fs():
+            rc = lib.vmf_rsample_fwd(_lib.ptr(mu1), 0, _lib.ptr(k1), 0, _lib.ptr(z), None, None, None, None, n, m, None, None,
+                                     0, None, 64, 0, 1, 0, None, 0, _lib.VMF_F32, sp)
+            assert rc == 0
+        ms = timeit(fs)
+        row(f"rsample fwd, one (mu, kappa) shared by all rows, m={m} n=2^{int(np.log2(n))} float32", ms, n * m * 4, n, "rows")
+        del z
+    torch.cuda.empty_cache()
+
     # --- m = 3 reference-exact path
     for n in (4096, 1 << 24):
         loc = torch.randn(n, 3, device=DEV, generator=g)
