@@ -742,11 +742,11 @@ def test_high_dim_regime_full_size_properties():
 
 
 def test_product_of_circles_and_s1_sampler_large():
-    """the product-of-circles configuration on one GPU at reduced row count (2^26 x 16 circles is the 8-GPU case): a product
-    of 16 von Mises circles per row = 16 independent m = 2 rows, plus the S^1 projected-normal sampler and the
-    I1/I0 KL on the same kappa"""
+    """the product-of-circles configuration at one GPU's full share (2^26 rows x 16 circles over 8 GPUs = 2^23 x 16 per
+    GPU): a product of 16 von Mises circles per row = 16 independent m = 2 rows, plus the S^1 projected-normal sampler
+    and the I1/I0 KL on the same kappa"""
     import scipy.stats as st
-    rows, circles = 1 << 18, 16
+    rows, circles = 1 << 23, 16
     n = rows * circles
     g = torch.Generator(device=DEV).manual_seed(3)
     ang = torch.rand(n, device=DEV, generator=g) * 2 * np.pi
