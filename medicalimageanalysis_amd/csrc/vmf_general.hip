@@ -7,9 +7,9 @@
 //   m > 256.  A wave therefore moves 64/LPR rows per step with fully coalesced 1 KiB loads and stores, and
 //   the three row reductions (|g|^2, |e1-mu|^2, <g,mu>) are DPP butterflies inside the LPR-lane group: no
 //   LDS traffic, no atomics.
-//   Each wave owns ONE tile of tile_rows(LPR) consecutive rows (grid = all tiles; workgroups are dispatched in index
-//   order, so the waves resident at any moment stream neighbouring memory).  Phase 1 (one row per lane) runs the rejection
-//   sampler for the tile's rows: lanes whose proposal was accepted retire the row (w goes to the wave's LDS
+//   Each wave owns ONE tile of tile_rows(LPR) consecutive rows (grid = all tiles; the block index is remapped so that
+//   each of the 8 XCDs walks one contiguous eighth of the tiles, see xcd_block in common.h).  Phase 1 (one row per
+//   lane) runs the rejection sampler for the tile's rows: lanes whose proposal was accepted retire the row (w goes to the wave's LDS
 //   slab) and are refilled with the next unassigned row of the tile through a ballot + prefix popcount, so
 //   the loop trip count follows the tile's MEAN number of proposals, not its maximum.  Phase 2 streams the
 //   rows: load mu (the next step's rows are prefetched while the current step computes), make m-1 normals from
@@ -622,9 +622,9 @@ static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   const bool full = vec && (passes == 1 || passes == 2 || passes == 4 || passes == 8) && m == 4 * lpr * passes;
   const int64_t n_tiles = (n + tile_rows(lpr) - 1) / tile_rows(lpr);
   int64_t gb = (n_tiles + WAVES - 1) / WAVES;
-  // One tile per wave, every tile its own wave: workgroups are dispatched in index order, so the waves in flight at
-  // any moment work on neighbouring tiles (DRAM-page and TLB locality).  A persistent grid of 2048 workgroups walking
-  // strided tiles measured 13 % slower on the same kernel body.
+  // One tile per wave, every tile its own wave: workgroups are dispatched in index order and the kernel maps them
+  // to tiles so that the waves in flight on one XCD work on neighbouring tiles.  A persistent grid of 2048 workgroups
+  // walking strided tiles measured 13 % slower on the same kernel body.
   VMF_REQUIRE(gb <= 0x7fffffff, VMF_ERR_UNSUPPORTED, "n=%lld rows need more than 2^31 workgroups", (long long)n);
   const int grid = (int)(gb < 1 ? 1 : gb);
   {
