@@ -224,6 +224,7 @@ template <> struct F<float> {
     *c = __builtin_amdgcn_cosf(u);
   }
   static __device__ __forceinline__ float cos2pi(float u) { return __builtin_amdgcn_cosf(u); }
+  static __device__ __forceinline__ float sin2pi(float u) { return __builtin_amdgcn_sinf(u); }
   // (log(1+s) - s) / ln 2 for s > -1, evaluated directly: the rounding of 1+s bounds the absolute error by
   // 2^-24 / ln 2, which the caller multiplies by (m-1) -- negligible against log2 of a uniform.
   static __device__ __forceinline__ float log1p_minus_over_ln2(float s) {
@@ -247,6 +248,7 @@ template <> struct F<double> {
   static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
   static __device__ __forceinline__ void sincos2pi(double u, double* s, double* c) { ::sincospi(2.0 * u, s, c); }
   static __device__ __forceinline__ double cos2pi(double u) { return ::cospi(2.0 * u); }
+  static __device__ __forceinline__ double sin2pi(double u) { return ::sinpi(2.0 * u); }
   static __device__ __forceinline__ double log1p_minus_over_ln2(double s) {
     double r;
     if (::fabs(s) < 1e-2) {

@@ -136,7 +136,7 @@ __device__ __forceinline__ void prefetch_wait(f32x4& dst) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(dst) : : "memory");
 }
 
-// The w / 1-w slabs are private to a wave: producer and consumer lanes belong to the same wave, whose LDS
+// The w / 1-w^2 slabs are private to a wave: producer and consumer lanes belong to the same wave, whose LDS
 // operations execute in program order.  All that is needed between the phases is that the compiler keeps that order
 // and that outstanding LDS operations have retired; no workgroup barrier, and no wait on global memory.
 __device__ __forceinline__ void wave_lds_sync() {
@@ -205,7 +205,7 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
           skp[i] = (float)kap;
           slc[i] = vmf_log_norm_f32v(p.lc_v, p.lc_lg, p.lc_c0, (float)kap);
         }
-        // b(kappa) of every row of the tile, coalesced, parked in the slab that later receives 1 - w
+        // b(kappa) of every row of the tile, coalesced, parked in the slab that later receives 1 - w^2
         if (!pre) somw[i] = wood_b<T>(kap, m);
       }
       wave_lds_sync();
@@ -222,10 +222,11 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
       while (__ballot(active) != 0ull) {
         bool acc = false;
         if (active) {
-          T w = 0, omw = 0, pc = 0, ps = 0;  // circle: cos^2 / den and sin^2 / den of the proposal kept
+          T w = 0, omw = 0, c2 = 0, pc = 0, ps = 0;  // circle: cos^2 / den and sin^2 / den of the proposal kept
           if (pre) {
             const int64_t row = tile0 + my;
             acc = wood_try<T>(a, b, d, m, p.prop_e[row * p.max_prop + k], p.prop_u[row * p.max_prop + k], &w, &omw);
+            c2 = omw * ((T)1 + w);
           } else if (LPR == 1 && circle) {
             // k is even here: both proposals of call k / 2 are evaluated in this iteration and the first accepted
             // one wins (the same decision sequence as one proposal per iteration, in half the Philox calls -- lanes
@@ -240,11 +241,11 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
             if (!use0) { pc = pc1; ps = ps1; ++k; }
           } else {
             const U4 r = philox4x32_10(grow0 + (uint64_t)my, (uint32_t)k, key);
-            acc = wood_try_counter<T>(b, m, u01<T>(r.x), u01<T>(r.y), u01<T>(r.z), &w, &omw);
+            acc = wood_try_counter<T>(b, m, u01<T>(r.x), u01<T>(r.y), u01<T>(r.z), &w, &omw, &c2);
           }
           if (k + 1 >= p.max_prop) acc = true;  // the last proposal allowed is taken regardless
           if (acc) {
-            T parked = omw;
+            T parked = c2;  // (1 - w)(1 + w), formed where 1 + w is known without cancellation
             if (LPR == 1 && circle) {
               parked = circle_pack((T)2 * b * pc, (T)2 * ps, neg);
               T opw;
@@ -357,15 +358,15 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
       const T d0 = (T)1 - mu0;
       const T tail = dd * (inv * inv);  // |mu|^2 without its first element
       dd = d0 * d0 + tail;              // |e1 - mu|^2
-      T w, omw, opw;  // w, 1 - w, 1 + w
+      T w, c2;  // w, 1 - w^2
       if (LPR == 1 && circle) {
+        T omw, opw;
         circle_unpack(somw[rr], &w, &omw, &opw);
+        c2 = omw * opw;
       } else {
-        omw = somw[rr];
+        c2 = somw[rr];
         w = sw[rr];
-        opw = (T)1 + w;
       }
-      T c2 = omw * opw;
       c2 = c2 < (T)1e-10 ? (T)1e-10 : c2;
       const T f = F<T>::sqrt(c2) * F<T>::rsqrt(gg);
       const T zd = w * d0 - f * gm;

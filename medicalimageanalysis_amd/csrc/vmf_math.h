@@ -389,16 +389,34 @@ VMF_HD bool wood_try(T a, T b, T d, int m, T e, T uacc, T* w, T* omw) {
 //   den = 1 - (1-b)(1+c)/2,  1 - w = b (1+c)/den,  w = 1 - (1-w)
 //   4ab/(1+b) = m-1 identically, so  (m-1) ln t - t + d = (m-1) [log(1+s) - s],  s = t/(m-1) - 1 = (1-b) c / (2 den)
 // and the test is (m-1)[log1p(s) - s] >= ln u.  Same decision as wood_try up to rounding.
+// The composition needs 1 - w^2 = (1-w)(1+w), and 1 + w = (1-c)/den loses its digits when formed from the rounded w
+// near w = -1 (m = 3 has density there: one row in ~10^6 at kappa = 1 came out 1e-4 off in fp32).  With q = U^(2/(m-2)),
+// r = sqrt(1-q) and V folded to its distance from the nearest integer,
+//   1 - c = (1 - r) + r (1 - cos 2 pi V) = q / (1 + r) + 2 r sin^2(pi V)
+// is a sum of two non-negative terms, so *c2 = (1-w)(1+w) keeps its relative accuracy everywhere (used for m <= 4:
+// the density at w = -1 is ~ (1+w)^((m-3)/2), so wider rows never draw a w that close and take the plain 1 - c).
 template <typename T>
-__device__ __forceinline__ bool wood_try_counter(T b, int m, T U, T V, T uacc, T* w, T* omw) {
-  T sq = (T)1;
-  if (m > 2) sq = F<T>::one_minus_exp2((T)2 / (T)(m - 2) * F<T>::log2(U));  // 1 - U^(2/(m-2))
-  const T c = F<T>::sqrt(sq) * F<T>::cos2pi(V);
+__device__ __forceinline__ bool wood_try_counter(T b, int m, T U, T V, T uacc, T* w, T* omw, T* c2) {
+  T sq = (T)1, q = (T)0;
+  if (m > 2) {
+    const T t = (T)2 / (T)(m - 2) * F<T>::log2(U);
+    sq = F<T>::one_minus_exp2(t);  // 1 - U^(2/(m-2))
+    q = F<T>::exp2(t);
+  }
+  const T rt = F<T>::sqrt(sq);
+  const T c = rt * F<T>::cos2pi(V);
+  T omc = (T)1 - c;
+  if (m <= 4) {  // from m = 5 on the density vanishes at w = -1 fast enough that no draw comes near it
+    const T Vf = V > (T)0.5 ? (T)1 - V : V;  // sin^2 pi V = sin^2 pi Vf, from a small argument at both ends
+    const T sh = F<T>::sin2pi((T)0.5 * Vf);
+    omc = q * F<T>::rcp((T)1 + rt) + (T)2 * rt * sh * sh;
+  }
   const T opc = (T)1 + c;
   const T den = (T)1 - (T)0.5 * ((T)1 - b) * opc;
   const T rden = F<T>::rcp(den);
   *omw = b * opc * rden;
   *w = (T)1 - *omw;
+  *c2 = *omw * (omc * rden);
   const T s = (T)0.5 * ((T)1 - b) * c * rden;
   return (T)(m - 1) * F<T>::log1p_minus_over_ln2(s) >= F<T>::log2(uacc);  // both sides divided by ln 2
 }

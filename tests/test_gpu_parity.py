@@ -991,6 +991,38 @@ def test_general_fp32_draws_and_gradients_agree_with_fp64(m):
     assert float((err_k[same] < 5e-3).float().mean()) > 0.999, float((err_k[same] < 5e-3).float().mean())
 
 
+def test_general_m3_fp32_keeps_its_digits_at_the_south_pole():
+    """m = 3 is the one general shape with density at w = -1: at small kappa one row in ~10^6 accepts a w within 1e-5
+    of -1, where sqrt(1 - w^2) formed from the rounded w is off by 1e-4 in fp32.  The kernel carries (1-w)(1+w) from
+    the proposal's cancellation-free form instead; 2^23 rows on the same counters in fp32 and fp64 must agree on
+    every row, those at the pole included (and the draw must contain such rows, or this test checks nothing)."""
+    lib, sp = _lib.lib(), _lib.stream_ptr(DEV)
+    g = torch.Generator(device=DEV).manual_seed(77)
+    n, m = 1 << 23, 3
+    mu = torch.nn.functional.normalize(torch.randn(n, m, device=DEV, dtype=torch.float64, generator=g), dim=-1).float()
+    kappa = (0.05 + 1.5 * torch.rand(n, device=DEV, dtype=torch.float64, generator=g)).float()
+
+    def run(dt):
+        a, k = mu.to(dt).contiguous(), kappa.to(dt).contiguous()
+        z, w = torch.empty_like(a), torch.empty_like(k)
+        idx = torch.empty(n, device=DEV, dtype=torch.int32)
+        _lib.check(lib.vmf_rsample_fwd(_lib.ptr(a), m, _lib.ptr(k), 1, _lib.ptr(z), _lib.ptr(w), None,
+                                       C.c_void_p(idx.data_ptr()), None, n, m, None, None, 0, None, 64, 0, 11, 3, None, 0,
+                                       _lib.dtype_code(a), sp), "vmf_rsample_fwd")
+        return z.double(), w.double(), idx
+
+    z32, w32, i32 = run(torch.float32)
+    z64, w64, i64 = run(torch.float64)
+    same = i32 == i64
+    assert float(same.float().mean()) > 0.9999
+    pole = same & (1 + w64 < 1e-5)
+    assert int(pole.sum()) >= 5, int(pole.sum())
+    err = (z32 - z64).abs().amax(dim=1)
+    assert float(err[pole].max()) < 5e-6, float(err[pole].max())
+    assert float(err[same].max()) < 2e-5, float(err[same].max())
+    assert float((z32.norm(dim=1) - 1).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("tag", ["f64", "f32"])
 @pytest.mark.parametrize("m", [2, 3, 10, 64, 512])
 def test_general_log_prob_entropy_kl(oracle, tag, m):
