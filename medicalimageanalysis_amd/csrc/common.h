@@ -312,6 +312,30 @@ __device__ __forceinline__ T group_allreduce_sum(T x) {
   return x;
 }
 
+// Three sums at once.  For float rows of 16 lanes the twelve DPP additions are written out by hand: left to itself the
+// compiler packs two of the three chains into v_pk_add_f32, which cannot take a DPP operand, and pays two DPP moves
+// per step for it (19 instructions instead of 12).  The three chains are interleaved so that every DPP read of a
+// register comes two instructions after the write to it (the wait states that hazard needs); the leading s_nop covers
+// the producers of the inputs.
+template <int LPR, typename T>
+__device__ __forceinline__ void group_allreduce_sum3(T& a, T& b, T& c) {
+  a = group_allreduce_sum<LPR, T>(a);
+  b = group_allreduce_sum<LPR, T>(b);
+  c = group_allreduce_sum<LPR, T>(c);
+}
+#define VMF_DPP3(ctrl)                                                   \
+  "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+  "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+  "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+template <>
+__device__ __forceinline__ void group_allreduce_sum3<16, float>(float& a, float& b, float& c) {
+  asm volatile("s_nop 1\n\t"
+               VMF_DPP3("quad_perm:[1,0,3,2]") VMF_DPP3("quad_perm:[2,3,0,1]") VMF_DPP3("row_half_mirror")
+               VMF_DPP3("row_mirror")
+               : "+v"(a), "+v"(b), "+v"(c));
+}
+#undef VMF_DPP3
+
 // block-wide sum in double; result valid in thread 0.  `red` must hold blockDim.x/64 doubles.
 __device__ __forceinline__ double block_sum_double(double x, double* red) {
   x = group_allreduce_sum<64, double>(x);

@@ -143,6 +143,7 @@ struct FwdParams {
 // keep this correct: the destination is touched by nothing between prefetch_issue() and prefetch_wait(); the wait
 // names the destination as an in/out operand so every use is ordered after it; vmcnt(0) over-waits at worst.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 // cache modifiers of the streaming kernel's mu load and z store.  A/B in one process on 2^24 x 64 rows (plain load +
 // plain store = 1.000): nt store 0.989, nt load + nt store 0.974, nt load + system-scope nt store 0.967; scope bits
 // without nt 0.985.  Every byte is touched once, so nothing is worth keeping in L2.
@@ -323,6 +324,7 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
 #pragma unroll
       for (int j = 0; j < P; ++j) cur[j] = pf[j];
     }
+    const T gmask0 = sub == 0 ? (T)0 : (T)1;
     for (int r0 = 0; r0 < ntile; r0 += RPI) {
       const int r = r0 + grp;
       const bool valid = r < ntile;
@@ -349,12 +351,15 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
         }
       }
       T gg = 0, dd = 0, gm = 0;
+      f32x2 gg2 = {0.0f, 0.0f}, dd2 = {0.0f, 0.0f}, gm2 = {0.0f, 0.0f};
 #pragma unroll
       for (int j = 0; j < P; ++j) {
         const int chunk = j * LPR + sub;
         if (FAST) {
           philox_normal4<T>(grow0 + (uint64_t)rr, SLOT_GAUSS + (uint32_t)chunk, key, g[j]);
-          if (j == 0 && sub == 0) g[0][0] = (T)0;
+          // element 0 carries no tangent noise; a multiplication by a lane constant (the normals are finite) rather
+          // than a select, which the compiler widens to the whole 4-vector
+          if (j == 0) g[0][0] *= gmask0;
         } else {
           if (CIRCLE) {
             const Pair<T> v = *reinterpret_cast<const Pair<T>*>(mrow);
@@ -369,17 +374,29 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
             noise4<T, VEC>(ga_t ? ga_t + (int64_t)rr * m : nullptr, grow0 + (uint64_t)rr, chunk, m, key, g[j]);
           }
         }
+        if (FAST && sizeof(T) == 4) {
+          // the three partial sums in packed pairs (v_pk_mul / v_pk_fma: two lanes of arithmetic per instruction)
+          const f32x2 ga = {(float)g[j][0], (float)g[j][1]}, gb = {(float)g[j][2], (float)g[j][3]};
+          const f32x2 ma = {(float)mu[j][0], (float)mu[j][1]}, mb = {(float)mu[j][2], (float)mu[j][3]};
+          f32x2 mq = ma;  // mu without its first element
+          if (j == 0) mq.x = sub == 0 ? 0.0f : ma.x;
+          gg2 = ga * ga + gg2; gg2 = gb * gb + gg2;
+          dd2 = mq * mq + dd2; dd2 = mb * mb + dd2;
+          gm2 = ga * ma + gm2; gm2 = gb * mb + gm2;  // g is zero at element 0
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bool first = (j == 0 && i == 0 && sub == 0);
-          gg += g[j][i] * g[j][i];
-          dd += first ? (T)0 : mu[j][i] * mu[j][i];  // |mu|^2 without its first element
-          gm += g[j][i] * mu[j][i];                   // g is zero at element 0
+          for (int i = 0; i < 4; ++i) {
+            const bool first = (j == 0 && i == 0 && sub == 0);
+            gg += g[j][i] * g[j][i];
+            dd += first ? (T)0 : mu[j][i] * mu[j][i];  // |mu|^2 without its first element
+            gm += g[j][i] * mu[j][i];                   // g is zero at element 0
+          }
         }
       }
-      gg = group_allreduce_sum<LPR, T>(gg);
-      dd = group_allreduce_sum<LPR, T>(dd);
-      gm = group_allreduce_sum<LPR, T>(gm);
+      if (FAST && sizeof(T) == 4) {
+        gg = (T)(gg2.x + gg2.y); dd = (T)(dd2.x + dd2.y); gm = (T)(gm2.x + gm2.y);
+      }
+      group_allreduce_sum3<LPR, T>(gg, dd, gm);
       T mu0 = LPR == 1 ? mu[0][0] : __shfl(mu[0][0], lane - sub, 64);
       // raw mean directions: everything below is written for mu / ||mu||; `inv` carries the scale to the elements
       // (the exact-fit streaming instantiation is kept free of this option: a run-time flag there costs 3 % of the
