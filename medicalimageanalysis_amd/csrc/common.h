@@ -335,6 +335,27 @@ __device__ __forceinline__ void group_allreduce_sum3<16, float>(float& a, float&
                : "+v"(a), "+v"(b), "+v"(c));
 }
 #undef VMF_DPP3
+// five sums (the backward pass), same construction
+template <int LPR, typename T>
+__device__ __forceinline__ void group_allreduce_sum5(T& a, T& b, T& c, T& d, T& e) {
+  group_allreduce_sum3<LPR, T>(a, b, c);
+  d = group_allreduce_sum<LPR, T>(d);
+  e = group_allreduce_sum<LPR, T>(e);
+}
+#define VMF_DPP5(ctrl)                                                   \
+  "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+  "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+  "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+  "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+  "v_add_f32_dpp %4, %4, %4 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+template <>
+__device__ __forceinline__ void group_allreduce_sum5<16, float>(float& a, float& b, float& c, float& d, float& e) {
+  asm volatile("s_nop 1\n\t"
+               VMF_DPP5("quad_perm:[1,0,3,2]") VMF_DPP5("quad_perm:[2,3,0,1]") VMF_DPP5("row_half_mirror")
+               VMF_DPP5("row_mirror")
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
+}
+#undef VMF_DPP5
 
 // block-wide sum in double; result valid in thread 0.  `red` must hold blockDim.x/64 doubles.
 __device__ __forceinline__ double block_sum_double(double x, double* red) {

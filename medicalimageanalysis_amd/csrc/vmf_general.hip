@@ -521,11 +521,7 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
         Gg += G[j][i] * g[j][i];
       }
     }
-    gg = group_allreduce_sum<LPR, T>(gg);
-    dd = group_allreduce_sum<LPR, T>(dd);
-    gm = group_allreduce_sum<LPR, T>(gm);
-    Gd = group_allreduce_sum<LPR, T>(Gd);
-    Gg = group_allreduce_sum<LPR, T>(Gg);
+    group_allreduce_sum5<LPR, T>(gg, dd, gm, Gd, Gg);
     T mu0 = __shfl(mu[0][0], lane - sub, 64);
     const T G0 = __shfl(G[0][0], lane - sub, 64);
     // raw mean directions: work with mu_hat = mu / ||mu|| (inv = 1 / ||mu||), chain through the normalisation below
