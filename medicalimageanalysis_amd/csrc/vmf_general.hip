@@ -7,7 +7,7 @@
 //   m > 256.  A wave therefore moves 64/LPR rows per step with fully coalesced 1 KiB loads and stores, and
 //   the three row reductions (|g|^2, |e1-mu|^2, <g,mu>) are DPP butterflies inside the LPR-lane group: no
 //   LDS traffic, no atomics.
-//   Each wave owns ONE tile of tile_rows(LPR) consecutive rows (grid = all tiles; the block index is remapped so that
+//   Each wave owns ONE tile of tile_rows(LPR, P) consecutive rows (grid = all tiles; the block index is remapped so that
 //   each of the 8 XCDs walks one contiguous eighth of the tiles, see xcd_block in common.h).  Phase 1 (one row per
 //   lane) runs the rejection sampler for the tile's rows: lanes whose proposal was accepted retire the row (w goes to the wave's LDS
 //   slab) and are refilled with the next unassigned row of the tile through a ballot + prefix popcount, so
@@ -50,7 +50,23 @@ constexpr int WAVES = VMF_WAVES;
 #ifndef VMF_TILE_ROWS_CIRCLE
 #define VMF_TILE_ROWS_CIRCLE 1024
 #endif
-constexpr int tile_rows(int lpr) { return lpr == 1 ? VMF_TILE_ROWS_LPR1 : (lpr <= 4 ? VMF_TILE_ROWS_NARROW : VMF_TILE_ROWS); }
+// Wide rows: the tile shrinks with the row so that a wave's footprint stays near VMF_TILE_ELEMS elements of mu and
+// of z (32 KiB each in fp32, what 128 rows of m = 64 are), but not below VMF_TILE_ROWS_MIN rows.  Against 128-row
+// tiles for every width (2^22 .. 2^23 rows, fp32): m = 128 1.667 -> 1.564 ms, m = 256 1.723 -> 1.543, m = 512
+// 3.365 -> 3.043, m = 1024 3.344 -> 3.009; twice the footprint gives back half of that, half the footprint is
+// 2-4 % slower again for m <= 256.
+#ifndef VMF_TILE_ELEMS
+#define VMF_TILE_ELEMS 8192
+#endif
+#ifndef VMF_TILE_ROWS_MIN
+#define VMF_TILE_ROWS_MIN 8
+#endif
+constexpr int tile_rows(int lpr, int passes) {
+  if (lpr == 1) return VMF_TILE_ROWS_LPR1;
+  if (lpr <= 4) return VMF_TILE_ROWS_NARROW;
+  const int fit = VMF_TILE_ELEMS / (4 * lpr * passes);
+  return fit >= VMF_TILE_ROWS ? VMF_TILE_ROWS : (fit < VMF_TILE_ROWS_MIN ? VMF_TILE_ROWS_MIN : fit);
+}
 constexpr uint32_t SLOT_GAUSS = 0x10000u;
 constexpr int BWD_STEPS = 16;
 
@@ -193,7 +209,7 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
   const PhiloxKey key = philox_resolve(p.ka);  // scalar: seed + host offset (+ device-resident offset)
   // the circle instantiation parks one word per row (see circle_pack), so its tiles can be
   // larger in the same LDS footprint
-  constexpr int TILE_ROWS = CIRCLE ? VMF_TILE_ROWS_CIRCLE : tile_rows(LPR);
+  constexpr int TILE_ROWS = CIRCLE ? VMF_TILE_ROWS_CIRCLE : tile_rows(LPR, P);
   __shared__ T s_w[WAVES][CIRCLE ? 1 : TILE_ROWS];
   __shared__ T s_omw[WAVES][TILE_ROWS];
   // fp32 fused log_prob: log C_m(kappa) and kappa of the tile's rows (kappa is read from HBM once per row)
@@ -666,7 +682,9 @@ static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   while (lpr < chunks && lpr < 64) lpr *= 2;
   const int passes = (chunks + lpr - 1) / lpr;
   const bool full = vec && (passes == 1 || passes == 2 || passes == 4 || passes == 8) && m == 4 * lpr * passes;
-  const int64_t n_tiles = (n + tile_rows(lpr) - 1) / tile_rows(lpr);
+  // the pass count of the instantiation VMF_SHAPE_SWITCH picks (a power of two), which sets the tile size
+  const int kpasses = chunks <= 64 ? 1 : (chunks <= 128 ? 2 : (chunks <= 256 ? 4 : 8));
+  const int64_t n_tiles = (n + tile_rows(lpr, kpasses) - 1) / tile_rows(lpr, kpasses);
   int64_t gb = (n_tiles + WAVES - 1) / WAVES;
   // One tile per wave, every tile its own wave: workgroups are dispatched in index order and the kernel maps them
   // to tiles so that the waves in flight on one XCD work on neighbouring tiles.  A persistent grid of 2048 workgroups

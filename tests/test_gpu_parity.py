@@ -662,15 +662,18 @@ def test_general_rsample_two_sample_ks_against_cpu_sampler(oracle):
             assert p > 1e-3, (m, kappa, comp, p)
 
 
-@pytest.mark.parametrize("m", [64, 2, 10])
+@pytest.mark.parametrize("m", [64, 2, 10, 128, 256, 512, 700, 1024, 2048])
 def test_general_rsample_every_row_written_once_for_any_grid(m):
     """the forward kernel walks its tiles in a remapped block order (one contiguous eighth of the grid per XCD, plain
     order for the ragged end): for grids of 1 .. 8k+r blocks every row must be produced exactly once -- the output is
     pre-filled with NaN, and the same rows drawn as two shards (other grid sizes, other remaps) must give the same bits"""
-    rows_per_block = {64: 4 * 128, 2: 4 * 512, 10: 4 * 320}[m]
+    # (wide rows take smaller tiles: about 8192 elements per wave, at least 8 rows; 700 = three passes' worth of
+    #  elements in the four-pass instantiation)
+    rows_per_block = {64: 4 * 128, 2: 4 * 512, 10: 4 * 320, 128: 4 * 64, 256: 4 * 32, 512: 4 * 16, 700: 4 * 8, 1024: 4 * 8,
+                      2048: 4 * 8}[m]
     lib, sp = _lib.lib(), _lib.stream_ptr(DEV)
     g = torch.Generator(device=DEV).manual_seed(5)
-    for nb in (1, 7, 8, 9, 15, 16, 17, 63, 64, 65, 1003):
+    for nb in ((1, 7, 8, 9, 15, 16, 17, 63, 64, 65, 1003) if m <= 64 else (1, 8, 9, 17, 65, 1003)):
         n = nb * rows_per_block - 5
         mu = torch.nn.functional.normalize(torch.randn(n, m, device=DEV, generator=g), dim=-1)
         kappa = torch.exp(torch.rand(n, device=DEV, generator=g) * np.log(1e3))
