@@ -68,7 +68,10 @@ constexpr int tile_rows(int lpr, int passes) {
   return fit >= VMF_TILE_ROWS ? VMF_TILE_ROWS : (fit < VMF_TILE_ROWS_MIN ? VMF_TILE_ROWS_MIN : fit);
 }
 constexpr uint32_t SLOT_GAUSS = 0x10000u;
-constexpr int BWD_STEPS = 16;
+#ifndef VMF_BWD_STEPS
+#define VMF_BWD_STEPS 16
+#endif
+constexpr int BWD_STEPS = VMF_BWD_STEPS;
 
 template <typename T>
 struct GenParams {
