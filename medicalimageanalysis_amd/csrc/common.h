@@ -375,6 +375,22 @@ struct alignas(2 * sizeof(T)) Pair {
   T a, b;
 };
 
+// streaming (non-temporal) access to a Pair: for arrays a kernel reads or writes exactly once
+template <typename T>
+__device__ __forceinline__ Pair<T> load_pair_nt(const T* base, int64_t i) {
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  const V2 v = __builtin_nontemporal_load(reinterpret_cast<const V2*>(base) + i);
+  Pair<T> r;
+  r.a = v.x; r.b = v.y;
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void store_pair_nt(T* base, int64_t i, T a, T b) {
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  const V2 v = {a, b};
+  __builtin_nontemporal_store(v, reinterpret_cast<V2*>(base) + i);
+}
+
 // 16-byte-aligned group of four values (one 128-bit access for float, two for double)
 template <typename T>
 struct alignas(sizeof(T) * 4 > 16 ? 16 : sizeof(T) * 4) Vec4 {

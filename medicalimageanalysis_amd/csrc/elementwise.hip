@@ -322,11 +322,12 @@ __global__ __launch_bounds__(256) void s1_projnormal2_kernel(const T* __restrict
   const PhiloxKey key = philox_resolve(ka);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const Pair<T> mu = reinterpret_cast<const Pair<T>*>(mean)[i];
-    const T k = kappa[i];
+    // every array is touched once: non-temporal accesses
+    const Pair<T> mu = load_pair_nt<T>(mean, i);
+    const T k = __builtin_nontemporal_load(kappa + i);
     T n0, n1;
     if (noise) {
-      const Pair<T> e = reinterpret_cast<const Pair<T>*>(noise)[i];
+      const Pair<T> e = load_pair_nt<T>(noise, i);
       n0 = e.a; n1 = e.b;
     } else {
       const U4 r = philox4x32_10(row0 + (uint64_t)i, 0x30000u, key);
@@ -336,27 +337,25 @@ __global__ __launch_bounds__(256) void s1_projnormal2_kernel(const T* __restrict
     T ss = 0;
     ss += y0 * y0;
     ss += y1 * y1;
-    T nn = M<T>::sqrt(ss);
+    // 1 / max(|y|, 1e-12): the 1-ulp hardware reciprocal square root for fp32, the library for fp64
+    T nn = F<T>::sqrt(ss);
     const bool clamped = nn < (T)1e-12;
-    if (clamped) nn = (T)1e-12;
+    const T rn = clamped ? (T)1e12 : F<T>::rsqrt(ss);
     if (!BWD) {
-      Pair<T> out;
-      out.a = y0 / nn; out.b = y1 / nn;
-      reinterpret_cast<Pair<T>*>(z)[i] = out;
+      store_pair_nt<T>(z, i, y0 * rn, y1 * rn);
     } else {
-      const Pair<T> g = reinterpret_cast<const Pair<T>*>(gz)[i];
+      const Pair<T> g = load_pair_nt<T>(gz, i);
       T yg = 0;
       yg += y0 * g.a;
       yg += y1 * g.b;
-      const T dy0 = clamped ? g.a / nn : g.a / nn - y0 * yg / (nn * nn * nn);
-      const T dy1 = clamped ? g.b / nn : g.b / nn - y1 * yg / (nn * nn * nn);
-      Pair<T> dm;
-      dm.a = k * dy0; dm.b = k * dy1;
-      reinterpret_cast<Pair<T>*>(dmean)[i] = dm;
+      const T t = clamped ? (T)0 : yg * (rn * rn * rn);
+      const T dy0 = g.a * rn - y0 * t;
+      const T dy1 = g.b * rn - y1 * t;
+      store_pair_nt<T>(dmean, i, k * dy0, k * dy1);
       T dk = 0;
       dk += mu.a * dy0;
       dk += mu.b * dy1;
-      dkappa[i] = dk;
+      __builtin_nontemporal_store(dk, dkappa + i);
     }
   }
 }
