@@ -485,7 +485,8 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
             slc[rr] += skp[rr] * (float)mz;  // written out coalesced once the tile is done
           } else if (sizeof(T) == 4) {       // circle: consecutive lanes hold consecutive rows
             const float kap = (float)kap_t[rr * p.kappa_stride];
-            p.logp[tile0 + rr] = (T)(vmf_log_norm_f32v(p.lc_v, p.lc_lg, p.lc_c0, kap) + kap * (float)mz);
+            const float lc = CIRCLE ? vmf_log_norm_circle_f32(kap) : vmf_log_norm_f32v(p.lc_v, p.lc_lg, p.lc_c0, kap);
+            p.logp[tile0 + rr] = (T)(lc + kap * (float)mz);
           } else {
             p.logp[tile0 + rr] += kap_t[rr * p.kappa_stride] * mz;  // log C_m(kappa) came from the pre-pass
           }
@@ -795,7 +796,8 @@ __global__ __launch_bounds__(256) void vmf_log_prob_rowterm_kernel(const T* __re
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const double k = (double)kappa[i * kappa_stride];
-    if (!BWD) out[i] = sizeof(T) == 4 ? (T)vmf_log_norm_f32(dim, (float)k) : (T)vmf_log_norm(dim, k);
+    if (!BWD) out[i] = sizeof(T) == 4 ? (T)(dim.m == 2 ? vmf_log_norm_circle_f32((float)k) : vmf_log_norm_f32(dim, (float)k))
+                                      : (T)vmf_log_norm(dim, k);
     else out[i] = (T)(-(double)gl[i] * vmf_mean_resultant(dim, k));  // d log C_m / dk = -A_m(k)
   }
 }

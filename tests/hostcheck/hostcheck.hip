@@ -32,6 +32,9 @@ void hc_log_norm_f32(int m, const float* k, float* out, int64_t n) {
   VmfDim d = make_vmf_dim(m);
   for (int64_t i = 0; i < n; ++i) out[i] = vmf_log_norm_f32(d, k[i]);
 }
+void hc_log_norm_circle_f32(const float* k, float* out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) out[i] = vmf_log_norm_circle_f32(k[i]);
+}
 #define HC_LATENT(NAME, T)                                                                                       \
   void NAME(const T* z, const T* labels, T* rows, T* dz, int64_t n, int zdim, int64_t nl, int lc, int variant,   \
             T R, T r) {                                                                                          \

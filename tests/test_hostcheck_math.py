@@ -88,6 +88,20 @@ def test_device_single_precision_log_normaliser(hc, oracle):
         np.testing.assert_allclose(out, ref, rtol=3e-6, atol=3e-6 * m)
 
 
+def test_device_circle_log_normaliser(hc, oracle):
+    """the circle's own fp32 log C_2(kappa) (Chebyshev i0e) against the double oracle, and against scipy's i0e"""
+    from scipy.special import i0e
+
+    lib = oracle.lib()
+    k = np.concatenate([np.logspace(-3, 5, 400), [7.999, 8.0, 8.001]]).astype(np.float32)
+    out = np.empty_like(k)
+    hc.hc_log_norm_circle_f32(_p(k), _p(out), C.c_int64(k.size))
+    ref = np.array([lib.orc_vmf_log_norm_scalar(2, float(kk)) for kk in k])
+    np.testing.assert_allclose(out, ref, rtol=3e-6, atol=6e-6)
+    kd = k.astype(np.float64)
+    np.testing.assert_allclose(out, -np.log(2 * np.pi) - np.log(i0e(kd)) - kd, rtol=3e-6, atol=6e-6)
+
+
 @pytest.mark.parametrize("tag", ["f64", "f32"])
 @pytest.mark.parametrize("name,variant", [("spherical", 0), ("torus", 1), ("circular", 2), ("s1", 3)])
 def test_device_kl_matches_reference(hc, golden, oracle, tag, name, variant):
