@@ -200,11 +200,11 @@ VMF_HD float log_ive_pos_f32(float v, float lgam_v1, float x) {
     const float q = 0.25f * x * x;
     float term = 1.0f, sum = 1.0f;
     for (int k = 1; k < 64; ++k) {
-      term *= q / ((float)k * (v + (float)k));
+      term *= q * fast_rcp((float)k * (v + (float)k));  // hardware reciprocal: 1 ulp per term, all terms positive
       sum += term;
       if (term < 1e-8f * sum) break;
     }
-    return v * ::logf(0.5f * x) - lgam_v1 - x + ::logf(sum);
+    return v * fast_log(0.5f * x) - lgam_v1 - x + fast_log(sum);
   }
   // Debye branch with the hardware log2 / reciprocal / rsqrt: this runs once per row inside the streaming sampler
   // (fused log_prob), where the libm versions cost 13 % more vector instructions per launch
