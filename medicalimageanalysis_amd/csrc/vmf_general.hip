@@ -68,10 +68,20 @@ constexpr int tile_rows(int lpr, int passes) {
   return fit >= VMF_TILE_ROWS ? VMF_TILE_ROWS : (fit < VMF_TILE_ROWS_MIN ? VMF_TILE_ROWS_MIN : fit);
 }
 constexpr uint32_t SLOT_GAUSS = 0x10000u;
-#ifndef VMF_BWD_STEPS
-#define VMF_BWD_STEPS 16
+// Consecutive steps a wave of the backward / log_prob kernels takes (a step = 64 / LPR rows).  log_prob: 16 for every
+// width.  Backward, measured per width on 2^21 .. 2^25 rows (ms at 1 / 2 / 4 / 8 / 16 / 32 steps): m = 16 1.26 / 1.16 /
+// 1.16 / 1.25 / 1.26 / 1.28; m = 64 2.35 / 2.21 / 2.20 / 2.36 / 2.33 / 2.28; m = 128 - / 2.25 / 2.23 / 2.36 / 2.32 /
+// 2.30; m = 256 flat (2.30 .. 2.35); m = 512 - / - / 4.65 / 4.63 / 4.42 / 4.86; m = 1024 - / 5.82 / 4.49 / 4.43 / 4.86 /
+// 5.39.  Hence 4, except the two-pass shape (16) and the four- and eight-pass shapes (8).
+#ifndef VMF_LP_STEPS
+#define VMF_LP_STEPS 16
 #endif
-constexpr int BWD_STEPS = VMF_BWD_STEPS;
+constexpr int LP_STEPS = VMF_LP_STEPS;
+#ifdef VMF_BWD_STEPS
+constexpr int bwd_steps(int, int) { return VMF_BWD_STEPS; }
+#else
+constexpr int bwd_steps(int lpr, int passes) { return (lpr < 64 || passes == 1) ? 4 : (passes == 2 ? 16 : 8); }
+#endif
 
 template <typename T>
 struct GenParams {
@@ -509,9 +519,10 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
   const int m = p.m;
   const int64_t n_steps = (p.n + RPI - 1) / RPI;
   const int64_t wave_id = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
-  // a wave takes BWD_STEPS consecutive steps; the grid covers all of them (neighbouring waves, neighbouring memory)
-  const int64_t step_end = (wave_id + 1) * BWD_STEPS < n_steps ? (wave_id + 1) * BWD_STEPS : n_steps;
-  for (int64_t step = wave_id * BWD_STEPS; step < step_end; ++step) {  // wave-uniform
+  // a wave takes STEPS consecutive steps; the grid covers all of them (neighbouring waves, neighbouring memory)
+  constexpr int STEPS = bwd_steps(LPR, P);
+  const int64_t step_end = (wave_id + 1) * STEPS < n_steps ? (wave_id + 1) * STEPS : n_steps;
+  for (int64_t step = wave_id * STEPS; step < step_end; ++step) {  // wave-uniform
     const int64_t r = step * RPI + grp;
     const bool valid = r < p.n;
     const int64_t row = valid ? r : 0;
@@ -758,7 +769,10 @@ static int rsample_bwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   int lpr = 1;
   while (lpr < chunks && lpr < 64) lpr *= 2;
   const int64_t steps = (n + (64 / lpr) - 1) / (64 / lpr);
-  const int64_t waves = (steps + BWD_STEPS - 1) / BWD_STEPS;
+  // the pass count of the instantiation VMF_SHAPE_SWITCH picks, which sets the steps per wave
+  const int kpasses = chunks <= 64 ? 1 : (chunks <= 128 ? 2 : (chunks <= 256 ? 4 : 8));
+  const int spw = bwd_steps(lpr, kpasses);
+  const int64_t waves = (steps + spw - 1) / spw;
   int64_t gb = (waves + WAVES - 1) / WAVES;
   VMF_REQUIRE(gb <= 0x7fffffff, VMF_ERR_UNSUPPORTED, "n=%lld rows need more than 2^31 workgroups", (long long)n);
   const int grid = (int)(gb < 1 ? 1 : gb);
@@ -817,8 +831,8 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_log_prob_dot_kernel(LogProbPar
   const int m = p.m;
   const int64_t n_steps = (p.n + RPI - 1) / RPI;
   const int64_t wave_id = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
-  const int64_t step_end = (wave_id + 1) * BWD_STEPS < n_steps ? (wave_id + 1) * BWD_STEPS : n_steps;
-  for (int64_t step = wave_id * BWD_STEPS; step < step_end; ++step) {  // wave-uniform
+  const int64_t step_end = (wave_id + 1) * LP_STEPS < n_steps ? (wave_id + 1) * LP_STEPS : n_steps;
+  for (int64_t step = wave_id * LP_STEPS; step < step_end; ++step) {  // wave-uniform
     const int64_t r = step * RPI + grp;
     const bool valid = r < p.n;
     const int64_t row = valid ? r : 0;
@@ -882,7 +896,7 @@ static int log_prob_t(const void* mu, int64_t mu_stride, const void* kappa, int6
   int lpr = 1;
   while (lpr < chunks && lpr < 64) lpr *= 2;
   const int64_t steps = (n + (64 / lpr) - 1) / (64 / lpr);
-  const int64_t waves = (steps + BWD_STEPS - 1) / BWD_STEPS;
+  const int64_t waves = (steps + LP_STEPS - 1) / LP_STEPS;
   int64_t gb = (waves + WAVES - 1) / WAVES;
   VMF_REQUIRE(gb <= 0x7fffffff, VMF_ERR_UNSUPPORTED, "n=%lld rows need more than 2^31 workgroups", (long long)n);
   const int grid = (int)(gb < 1 ? 1 : gb);

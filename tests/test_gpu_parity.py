@@ -693,6 +693,35 @@ def test_general_rsample_every_row_written_once_for_any_grid(m):
         assert torch.equal(torch.cat(parts), z), (m, nb)
 
 
+@pytest.mark.parametrize("m", [2, 10, 64, 256, 512, 700, 1024, 2048])
+def test_general_backward_writes_every_row_for_any_size(m):
+    """the backward kernel gives each wave a width-dependent number of consecutive steps and the host sizes the grid
+    from the same rule: for row counts around the step / workgroup boundaries every gradient row must be written
+    (outputs pre-filled with NaN), and a prefix of the rows must give the same bits as the full launch"""
+    lib, sp = _lib.lib(), _lib.stream_ptr(DEV)
+    g = torch.Generator(device=DEV).manual_seed(8)
+    for n in (1, 63, 64, 65, 255, 257, 1023, 4099, 20011):
+        mu = torch.nn.functional.normalize(torch.randn(n, m, device=DEV, generator=g), dim=-1)
+        kappa = torch.exp(torch.rand(n, device=DEV, generator=g) * np.log(1e3))
+        gz = torch.randn(n, m, device=DEV, generator=g)
+        z, w, omw = torch.empty_like(mu), torch.empty_like(kappa), torch.empty_like(kappa)
+        _lib.check(lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(z), _lib.ptr(w), _lib.ptr(omw), None,
+                                       None, n, m, None, None, 0, None, 64, 0, 7, 3, None, 0, _lib.VMF_F32, sp), "fwd")
+
+        def bwd(k):
+            dmu = torch.full((k, m), float("nan"), device=DEV)
+            dk = torch.full((k,), float("nan"), device=DEV)
+            _lib.check(lib.vmf_rsample_bwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(w), _lib.ptr(omw), _lib.ptr(gz), None,
+                                           _lib.ptr(dmu), _lib.ptr(dk), k, m, 0, 7, 3, None, 0, _lib.VMF_F32, sp), "bwd")
+            return dmu, dk
+
+        dmu, dk = bwd(n)
+        assert bool(torch.isfinite(dmu).all()) and bool(torch.isfinite(dk).all()), (m, n)
+        k = max(1, (2 * n) // 3)
+        dmu2, dk2 = bwd(k)
+        assert torch.equal(dmu2, dmu[:k]) and torch.equal(dk2, dk[:k]), (m, n)
+
+
 def test_general_rsample_full_size_properties():
     """the headline configuration at full size, m = 64 and 2^24 rows, through size-independent properties: unit norm,
     <z,mu> = w, E[w] = A_m(kappa), shard-invariance of the tail rows"""
