@@ -608,7 +608,7 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
         if (VEC && sizeof(T) == 4) {
           if (4 * (j * LPR + sub) < m) {
             f32x4 v4 = {(float)out[j][0], (float)out[j][1], (float)out[j][2], (float)out[j][3]};
-            __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(drow + 4 * (j * LPR + sub)));
+            store_nt(v4, reinterpret_cast<float*>(drow + 4 * (j * LPR + sub)));
           }
         } else {
           store4<T, VEC>(drow, 4 * (j * LPR + sub), m, out[j]);
