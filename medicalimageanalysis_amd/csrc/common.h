@@ -334,6 +334,22 @@ __device__ __forceinline__ void group_allreduce_sum3<16, float>(float& a, float&
                VMF_DPP3("row_mirror")
                : "+v"(a), "+v"(b), "+v"(c));
 }
+// narrower rows: the first stages only
+template <>
+__device__ __forceinline__ void group_allreduce_sum3<8, float>(float& a, float& b, float& c) {
+  asm volatile("s_nop 1\n\t"
+               VMF_DPP3("quad_perm:[1,0,3,2]") VMF_DPP3("quad_perm:[2,3,0,1]") VMF_DPP3("row_half_mirror")
+               : "+v"(a), "+v"(b), "+v"(c));
+}
+template <>
+__device__ __forceinline__ void group_allreduce_sum3<4, float>(float& a, float& b, float& c) {
+  asm volatile("s_nop 1\n\t" VMF_DPP3("quad_perm:[1,0,3,2]") VMF_DPP3("quad_perm:[2,3,0,1]")
+               : "+v"(a), "+v"(b), "+v"(c));
+}
+template <>
+__device__ __forceinline__ void group_allreduce_sum3<2, float>(float& a, float& b, float& c) {
+  asm volatile("s_nop 1\n\t" VMF_DPP3("quad_perm:[1,0,3,2]") : "+v"(a), "+v"(b), "+v"(c));
+}
 #undef VMF_DPP3
 // five sums (the backward pass), same construction
 template <int LPR, typename T>
