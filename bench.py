@@ -40,7 +40,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # the GPU needs ~10 launches of this size to settle its clocks (per-dispatch times in profiles/: 2.2, 2.0, 1.9 ...
-    # then 1.67-1.72 ms), hence the default warm-up
+    # then 1.53-1.56 ms), hence the default warm-up
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows", type=int, default=1 << 24, help="rows per GPU")
