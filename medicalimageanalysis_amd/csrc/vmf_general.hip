@@ -223,8 +223,8 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
   // the circle instantiation parks one word per row (see circle_pack), so its tiles can be
   // larger in the same LDS footprint
   constexpr int TILE_ROWS = CIRCLE ? VMF_TILE_ROWS_CIRCLE : tile_rows(LPR, P);
-  __shared__ T s_w[WAVES][CIRCLE ? 1 : TILE_ROWS];
-  __shared__ T s_omw[WAVES][TILE_ROWS];
+  // one array for both slabs, so that phase 2 fetches a row's w and 1 - w^2 with a single two-address LDS read
+  __shared__ T s_wc[WAVES][CIRCLE ? 1 : 2][TILE_ROWS];
   // fp32 fused log_prob: log C_m(kappa) and kappa of the tile's rows (kappa is read from HBM once per row)
   // (not for the circle: one lane owns a row there, so log p is formed and stored in phase 2 directly)
   constexpr bool LP_SLAB = sizeof(T) == 4 && !CIRCLE;
@@ -241,8 +241,8 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
   // phase 2 in the sign bit of the parked word (see circle_pack).
   // MODE 3 is this case with m a compile-time 2 and 64-bit accesses; MODE 0 takes it when rows are not 8-byte aligned.
   const bool circle = CIRCLE || (LPR == 1 && MODE == 0 && m == 2 && !pre && p.gauss == nullptr);
-  T* const sw = s_w[wave];
-  T* const somw = s_omw[wave];
+  T* const somw = s_wc[wave][0];
+  T* const sw = s_wc[wave][CIRCLE ? 0 : 1];  // not used by the circle instantiation
   float* const slc = s_lc[LP_SLAB ? wave : 0];
   float* const skp = s_kp[LP_SLAB ? wave : 0];
 
