@@ -4,7 +4,7 @@ At the reference's batch sizes (B = 128, latent S^2) a VAE step is ~100 tiny lau
 Every entry point of libvmf_hip.so is asynchronous, allocation-free and never synchronises, so forward + loss +
 backward + optimizer step can be captured once and replayed as one graph launch.  Noise stays fresh across replays:
 torch's generator is capture-aware (VMF_RNG=torch), and the in-kernel Philox streams read their call counter from
-device memory (rng.PhiloxGenerator.enable_device_counter).
+device memory (rng.PhiloxGenerator.enable_device_counter, which GraphedTrainStep always turns on).
 """
 import torch
 
@@ -28,8 +28,9 @@ class GraphedTrainStep:
         dev = self.static_inputs[0].device
         if dev.type != "cuda":
             raise RuntimeError("GraphedTrainStep runs on a HIP device only")
-        if rng.rng_mode() == "philox":
-            (generator or rng.default_generator).enable_device_counter(dev)
+        # unconditionally: the general-m sampler and HypersphericalUniform draw from the in-kernel streams whatever
+        # VMF_RNG says, and a host counter cannot be captured (harmless when nothing uses it)
+        (generator or rng.default_generator).enable_device_counter(dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):  # warm-up off the capture stream: lazy initialisations, optimizer state

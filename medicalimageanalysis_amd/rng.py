@@ -61,7 +61,8 @@ class PhiloxGenerator:
                     raise RuntimeError(
                         "in-kernel noise under HIP graph capture needs a device-resident counter (a captured host "
                         "offset would replay identical noise): call generator.enable_device_counter(device) before "
-                        "capturing, or draw the noise with torch (VMF_RNG=torch)")
+                        "capturing (graph.GraphedTrainStep does).  VMF_RNG=torch moves only VonMisesFisher3D / "
+                        "SphericalUniform / S1 noise to torch; the general-m sampler always uses this counter")
                 o = self.offset
                 self.offset = (self.offset + 1) & 0xFFFFFFFFFFFFFFFF
                 return self.seed, o, None

@@ -1214,6 +1214,39 @@ def test_circular_vae_golden(golden, monkeypatch):
             np.testing.assert_allclose(N(got), g[k], rtol=1e-7, atol=1e-10, err_msg=k)
 
 
+def test_circular_vae_through_flat_module_names(golden, monkeypatch):
+    """the CNN experiment imports by bare file name (CNN_experiment/circular_VAE.py:5, train_experiment.py:9):
+    `install_aliases(flat=True)` serves those names, and the model built through them reproduces the golden step"""
+    import sys
+
+    import medicalimageanalysis_amd as pkg
+    monkeypatch.setenv("VMF_RNG", "torch")
+    names = ("sampler", "model", "von_mises_fisher", "ive", "circular_VAE", "s1_vae")
+    saved = {k: v for k, v in sys.modules.items() if k.split(".")[0] in names}
+    try:
+        pkg.install_aliases(flat=True)
+        ns = {}
+        exec("from von_mises_fisher import *\nfrom circular_VAE import CircularVAE\n", ns)
+        g = golden("g_cvae")
+        cfg = {k[5:]: g[k].item() for k in g.files if k.startswith("cfg::")}
+        cfg["device"] = "cuda"
+        model = ns["CircularVAE"](cfg).double().to(DEV)
+        model.load_state_dict({k[3:]: T(g[k]) for k in g.files if k.startswith("w::")})
+        x = T(g["x"])
+        p1, p2 = _noise_feeder([(T(g["u"]), T(g["eps"]))])
+        with p1, p2:
+            z, x_recon, params = model(x)
+        np.testing.assert_allclose(N(z), g["z"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(N(model._elbo(x, x_recon, params)), g["loss"], rtol=1e-10)
+        # the flat VonMisesFisher3D is the CNN copy: it has log_prob (CNN_experiment/von_mises_fisher.py:88-95)
+        q = ns["VonMisesFisher3D"](params[0].detach(), params[1].detach())
+        assert q.log_prob(z.detach()).shape == (7,)
+    finally:
+        for k in [k for k in sys.modules if k.split(".")[0] in names]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
 def test_s1_vae_golden(golden, monkeypatch):
     monkeypatch.setenv("VMF_RNG", "torch")
     g = golden("g_s1")
@@ -1407,6 +1440,37 @@ def test_graphed_train_step_matches_eager_steps():
     with pytest.raises(ValueError, match="capturable"):
         m2 = SphericalVAE(cfg)
         GraphedTrainStep(m2, torch.optim.Adam(m2.parameters()), loss_fn, [x])
+
+
+def test_graphed_general_m_step_under_default_torch_rng(monkeypatch):
+    """The general-m sampler always draws from the in-kernel Philox streams, whatever VMF_RNG says, so a graphed
+    HypersphericalVAE step needs the device-resident counter in the default mode too: a fresh generator, VMF_RNG=torch,
+    capture must succeed and every replay must draw new noise."""
+    from medicalimageanalysis_amd.graph import GraphedTrainStep
+    from medicalimageanalysis_amd.model.hyperspherical_vae import HypersphericalVAE
+    monkeypatch.setenv("VMF_RNG", "torch")
+    cfg = dict(extrinsic_dim=784, latent_dim=10, sftbeta=1.0, encoder_width=64, encoder_depth=2, decoder_width=64,
+               decoder_depth=2, dropout_p=0.0, device="cuda", gamma=1.0, beta=0.01)
+    x = torch.rand(128, 784, device=DEV)
+
+    def loss_fn(model, xb):
+        z, x_mu, params = model(xb)
+        return model._elbo(xb, x_mu, params)
+
+    old = rng.default_generator
+    try:
+        rng.default_generator = rng.PhiloxGenerator(seed=11)   # host counter, as in a fresh process
+        torch.manual_seed(0)
+        model = HypersphericalVAE(cfg)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+        step = GraphedTrainStep(model, opt, loss_fn, [x], warmup=2)
+        losses = [float(step(x)) for _ in range(8)]
+        off = rng.default_generator.get_state()["offset"]
+    finally:
+        rng.default_generator = old
+    assert np.isfinite(losses).all() and len(set(losses)) == len(losses)
+    assert off == 2 + 8, off  # one sampling call per step: 2 warm-up steps, the capture records, 8 replays
+    assert losses[-1] < losses[0]
 
 
 def test_error_conventions():

@@ -121,10 +121,22 @@ def test_generator_state_roundtrip():
     assert g.next_offset() == (9, 0)
 
 
+def _alias_sandbox():
+    """snapshot of the module names install_aliases() may touch"""
+    names = ("sampler", "model", "dataloader", "von_mises_fisher", "ive", "circular_VAE", "s1_vae")
+    return {k: v for k, v in sys.modules.items() if k.split(".")[0] in names}, names
+
+
+def _alias_restore(saved, names):
+    for k in [k for k in sys.modules if k.split(".")[0] in names]:
+        del sys.modules[k]
+    sys.modules.update(saved)
+
+
 def test_reference_module_names_resolve():
     import medicalimageanalysis_amd as pkg
 
-    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k.split(".")[0] in ("sampler", "model")}
+    saved, names = _alias_sandbox()
     try:
         pkg.install_aliases()
         ns = {}
@@ -134,10 +146,67 @@ def test_reference_module_names_resolve():
         # the reference's model files rely on these names arriving through the star import
         for name in ("math", "torch", "ive", "Distribution", "constraints", "VonMisesFisher3D", "SphericalUniform"):
             assert name in ns, name
+        assert "von_mises_fisher" not in sys.modules and "ive" not in sys.modules  # generic names are opt-in
     finally:
-        for k in [k for k in sys.modules if k.split(".")[0] in ("sampler", "model")]:
-            del sys.modules[k]
-        sys.modules.update({k: v for k, v in saved.items() if v is not None})
+        _alias_restore(saved, names)
+
+
+def test_aliases_leave_the_callers_own_model_package_alone(tmp_path):
+    """main.py:1-6 and model/train.py:1-2, model/infer.py:1-3 of the reference import `model.train`, `model.infer`
+    and `dataloader.utils` next to the two model files this package replaces: after install_aliases() the caller's
+    own `model/` directory must still serve the files that are not replaced."""
+    import medicalimageanalysis_amd as pkg
+
+    (tmp_path / "model").mkdir()
+    (tmp_path / "dataloader").mkdir()
+    (tmp_path / "dataloader" / "data.py").write_text("DATA_MARK = 1\n")
+    (tmp_path / "dataloader" / "utils.py").write_text("from dataloader.data import *\nUTILS_MARK = 2\n")
+    # the import lines of the reference's model/train.py:1-2 and model/infer.py:1-3, then one own name each
+    (tmp_path / "model" / "train.py").write_text(
+        "from model.spherical_vae import *\nfrom dataloader.utils import * \nTRAIN_MARK = SphericalVAE.__module__\n")
+    (tmp_path / "model" / "infer.py").write_text(
+        "from model.spherical_vae import *\nfrom dataloader.utils import * \nfrom model.torus_vae import *\n"
+        "INFER_MARK = ToroidalVAE.__module__\n")
+    # a stale copy of a replaced file in the caller's tree must lose against the alias
+    (tmp_path / "model" / "spherical_vae.py").write_text("raise ImportError('the reference file was imported')\n")
+    saved, names = _alias_sandbox()
+    _alias_restore({}, names)
+    sys.path.insert(0, str(tmp_path))
+    try:
+        pkg.install_aliases()
+        ns = {}
+        exec("from dataloader.data import *\nfrom dataloader.utils import *\nfrom model.torus_vae import *\n"
+             "from model.train import *\nfrom model.spherical_vae import *\nfrom model.infer import *\n", ns)  # main.py:1-6
+        assert ns["TRAIN_MARK"] == "medicalimageanalysis_amd.model.spherical_vae"
+        assert ns["INFER_MARK"] == "medicalimageanalysis_amd.model.torus_vae"
+        assert ns["DATA_MARK"] == 1 and ns["UTILS_MARK"] == 2
+        assert sys.modules["model.train"].__file__.startswith(str(tmp_path))
+        import model
+        assert model.spherical_vae is sys.modules["medicalimageanalysis_amd.model.spherical_vae"]
+    finally:
+        sys.path.remove(str(tmp_path))
+        _alias_restore(saved, names)
+
+
+def test_flat_module_names_of_the_cnn_and_s1_experiments():
+    """CNN_experiment/circular_VAE.py:5 (`from von_mises_fisher import *`), CNN_experiment/von_mises_fisher.py:3
+    (`from ive import ive`), CNN_experiment/train_experiment.py:9, regular_cnn/main.py:11"""
+    import medicalimageanalysis_amd as pkg
+    from medicalimageanalysis_amd.sampler.von_mises_fisher import VonMisesFisher3DLogProb
+
+    saved, names = _alias_sandbox()
+    try:
+        pkg.install_aliases(flat=True)
+        ns = {}
+        exec("from von_mises_fisher import *\nfrom ive import ive\nfrom circular_VAE import CircularVAE\n"
+             "from s1_vae import S1_VAE, loss_function\n", ns)
+        assert ns["VonMisesFisher3D"] is VonMisesFisher3DLogProb and hasattr(ns["VonMisesFisher3D"], "log_prob")
+        for name in ("math", "torch", "ive", "Distribution", "constraints", "CircularVAE", "S1_VAE", "loss_function"):
+            assert name in ns, name
+        import ive as flat_ive
+        assert {"IveFunction", "Ive", "ive"} <= set(dir(flat_ive))
+    finally:
+        _alias_restore(saved, names)
 
 
 def test_shard_rows_cover_and_order():
