@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VMF_HIP_VERSION 120
+#define VMF_HIP_VERSION 130
 
 typedef void* vmf_stream_t; /* hipStream_t */
 
@@ -131,6 +131,18 @@ int vmf_bessel_ratio_fwd(double v, const void* z, void* out, int64_t n, int dtyp
 #define VMF_KL_WORKSPACE_DOUBLES 1024
 int vmf_kl_fwd(const void* kappa, void* out, double* sum_out, double* workspace, double alpha, int64_t n,
                int variant, int dtype, vmf_stream_t stream);
+/* vmf_kl_fwd without the workspace argument.  No counterpart in the reference: it is for callers that cannot
+ * allocate device memory -- a stream under HIP graph capture, a tight serving loop, a harness that forbids hipMalloc.
+ * The block partials of the fused sum live in an array inside the library's code object (VMF_KL_WORKSPACE_DOUBLES
+ * doubles = 8 KiB on every GPU the library runs on, until the process ends); the call allocates nothing.  Same
+ * kernels, same launch geometry and therefore the same bits as vmf_kl_fwd.  n <= VMF_KL_STATIC_MAX_N, larger sizes
+ * are refused (VMF_ERR_UNSUPPORTED).  Every call on one GPU shares that GPU's array: calls that may overlap there
+ * (different streams) race on it -- order them, or give the overlapping ones vmf_kl_fwd with workspaces of their own.
+ * Nothing in the array needs clearing between calls.  The first call on a device looks the array's address up
+ * (hipGetSymbolAddress); make it before a capture begins. */
+#define VMF_KL_STATIC_MAX_N ((int64_t)1 << 30)
+int vmf_kl_fwd_static(const void* kappa, void* out, double* sum_out, double alpha, int64_t n, int variant, int dtype,
+                      vmf_stream_t stream);
 /* dkappa[i] = gout_i * dKL/dkappa(kappa_i); gout is per element (gout_stride = 1) or one scalar
  * (gout_stride = 0), in the call's dtype; gscale multiplies it (1/n for the fused mean). */
 int vmf_kl_bwd(const void* kappa, const void* gout, int64_t gout_stride, double gscale, void* dkappa, int64_t n,

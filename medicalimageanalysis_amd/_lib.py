@@ -16,6 +16,7 @@ VMF_F32, VMF_F64 = 0, 1
 FLAG_NORMALIZE_MU = 1
 KL_SPHERICAL_PIECEWISE, KL_TORUS_RAW, KL_CIRCULAR_EPS, KL_S1_I0I1, KL_STABLE_M3, KL_STABLE_M2 = range(6)
 KL_WORKSPACE_DOUBLES = 1024
+KL_STATIC_MAX_N = 1 << 30
 ELBO_WORKSPACE_DOUBLES = 2048
 LATENT_S1, LATENT_S2, LATENT_T2 = range(3)
 
@@ -37,6 +38,7 @@ _PROTOS = {
     "vmf_log_ive_fwd": [_D, _P, _P, _I64, _I, _P],
     "vmf_bessel_ratio_fwd": [_D, _P, _P, _I64, _I, _P],
     "vmf_kl_fwd": [_P, _P, _P, _P, _D, _I64, _I, _I, _P],
+    "vmf_kl_fwd_static": [_P, _P, _P, _D, _I64, _I, _I, _P],
     "vmf_kl_bwd": [_P, _P, _I64, _D, _P, _I64, _I, _I, _P],
     "vmf_rsample_fwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _I, _P, _I, _U64, _U64, _U64, _P,
                         _I, _I, _P],

@@ -1,6 +1,9 @@
 // elementwise.hip -- ive / log_ive / Bessel ratio, the KL variants with their fused sum, the uniform prior
 // on the sphere and the S^1 projected-normal sampler.  All are streams over kappa / rows: read once, write
 // once, grid capped at 2048 workgroups with a grid-stride loop.
+#include <atomic>
+#include <mutex>
+
 #include "vmf_math.h"
 
 // ---- ive ---------------------------------------------------------------------------------------------
@@ -174,35 +177,89 @@ __global__ __launch_bounds__(256) void kl_bwd_kernel(const T* __restrict__ kappa
 
 static inline bool ew_aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-extern "C" int vmf_kl_fwd(const void* kappa, void* out, double* sum_out, double* workspace, double alpha,
-                          int64_t n, int variant, int dtype, vmf_stream_t stream) {
-  VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
+// shared by vmf_kl_fwd (caller's workspace) and vmf_kl_fwd_static (the library's own scratch array)
+static int kl_fwd_launch(const char* who, const void* kappa, void* out, double* sum_out, double* workspace,
+                         double alpha, int64_t n, int variant, int dtype, hipStream_t stream) {
+  VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "%s: n < 0", who);
   VMF_REQUIRE(variant >= 0 && variant <= VMF_KL_STABLE_M2, VMF_ERR_BAD_ARG, "unknown KL variant %d", variant);
-  VMF_REQUIRE(!sum_out || workspace, VMF_ERR_BAD_ARG, "vmf_kl_fwd: sum_out needs a workspace");
+  VMF_REQUIRE(!sum_out || workspace, VMF_ERR_BAD_ARG, "%s: sum_out needs a workspace", who);
   VMF_REQUIRE(dtype == VMF_F32 || dtype == VMF_F64, VMF_ERR_DTYPE, "dtype %d", dtype);
-  VMF_REQUIRE(n == 0 || kappa, VMF_ERR_BAD_ARG, "vmf_kl_fwd: null kappa");
+  VMF_REQUIRE(n == 0 || kappa, VMF_ERR_BAD_ARG, "%s: null kappa", who);
   KlBessel kb = make_kl_bessel();
   int grid = vmf_grid_for(dtype == VMF_F32 ? (n + 3) / 4 : n, 256, VMF_KL_WORKSPACE_DOUBLES);
   if (n > 0) {
     if (dtype == VMF_F32 && ew_aligned16(kappa) && ew_aligned16(out)) {
       // fp32: every variant has a single-precision form, so this instantiation leaves the double-precision Bessel
       // code out (46 instead of 149 VGPRs)
-      hipLaunchKernelGGL((kl_fwd_kernel<float, 4, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                         (const float*)kappa, (float*)out, sum_out ? workspace : nullptr, n, variant, kb);
+      hipLaunchKernelGGL((kl_fwd_kernel<float, 4, false>), dim3(grid), dim3(256), 0, stream, (const float*)kappa,
+                         (float*)out, sum_out ? workspace : nullptr, n, variant, kb);
     } else {
-      VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((kl_fwd_kernel<T, 1, true>), dim3(grid), dim3(256), 0,
-                                                   (hipStream_t)stream, (const T*)kappa, (T*)out,
-                                                   sum_out ? workspace : nullptr, n, variant, kb));
+      VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((kl_fwd_kernel<T, 1, true>), dim3(grid), dim3(256), 0, stream,
+                                                   (const T*)kappa, (T*)out, sum_out ? workspace : nullptr, n,
+                                                   variant, kb));
     }
-    int rc = vmf_check_launch("vmf_kl_fwd");
+    int rc = vmf_check_launch(who);
     if (rc) return rc;
   }
   if (sum_out) {
-    hipLaunchKernelGGL(kl_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, n > 0 ? grid : 0,
-                       alpha, sum_out);
-    return vmf_check_launch("vmf_kl_fwd final");
+    // every block of the first launch has written its partial; the finish reads exactly those `grid` words, so the
+    // workspace needs no clearing whatever an earlier call left in it
+    hipLaunchKernelGGL(kl_final_kernel, dim3(1), dim3(256), 0, stream, workspace, n > 0 ? grid : 0, alpha, sum_out);
+    return vmf_check_launch(who);
   }
   return VMF_OK;
+}
+
+extern "C" int vmf_kl_fwd(const void* kappa, void* out, double* sum_out, double* workspace, double alpha,
+                          int64_t n, int variant, int dtype, vmf_stream_t stream) {
+  return kl_fwd_launch("vmf_kl_fwd", kappa, out, sum_out, workspace, alpha, n, variant, dtype, (hipStream_t)stream);
+}
+
+// ---- vmf_kl_fwd without a workspace argument: the block partials live in an array of the code object ----------------
+// For callers that cannot allocate device memory (a stream under HIP graph capture, a serving loop, a harness that
+// forbids hipMalloc).  Each GPU the library runs on holds its own copy of the array, at its own address, until the
+// process ends; the array's name is only a host-side handle, so the device address is looked up once per device
+// (hipGetSymbolAddress, with that device current) and that pointer is what the kernels receive.
+static __device__ __align__(256) double vmf_kl_static_scratch[VMF_KL_WORKSPACE_DOUBLES];
+
+constexpr int VMF_MAX_DEVICES = 64;
+static std::atomic<double*> g_kl_scratch_ptr[VMF_MAX_DEVICES];
+static std::mutex g_kl_scratch_lock;
+
+// device address of the scratch array on the current device (resolved on the first call there)
+static int kl_static_scratch(double** ptr_out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  VMF_REQUIRE(e == hipSuccess, VMF_ERR_LAUNCH, "vmf_kl_fwd_static: hipGetDevice: %s", hipGetErrorString(e));
+  VMF_REQUIRE(dev >= 0 && dev < VMF_MAX_DEVICES, VMF_ERR_UNSUPPORTED, "vmf_kl_fwd_static: device %d >= %d", dev,
+              VMF_MAX_DEVICES);
+  double* p = g_kl_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!p) {
+    std::lock_guard<std::mutex> hold(g_kl_scratch_lock);
+    p = g_kl_scratch_ptr[dev].load(std::memory_order_relaxed);
+    if (!p) {
+      e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(vmf_kl_static_scratch));
+      VMF_REQUIRE(e == hipSuccess && p, VMF_ERR_LAUNCH, "vmf_kl_fwd_static: hipGetSymbolAddress on device %d: %s", dev,
+                  hipGetErrorString(e));
+      g_kl_scratch_ptr[dev].store(p, std::memory_order_release);
+    }
+  }
+  *ptr_out = p;
+  return VMF_OK;
+}
+
+extern "C" int vmf_kl_fwd_static(const void* kappa, void* out, double* sum_out, double alpha, int64_t n, int variant,
+                                 int dtype, vmf_stream_t stream) {
+  VMF_REQUIRE(n <= VMF_KL_STATIC_MAX_N, VMF_ERR_UNSUPPORTED,
+              "vmf_kl_fwd_static: n=%lld exceeds VMF_KL_STATIC_MAX_N=%lld (use vmf_kl_fwd with a caller workspace)",
+              (long long)n, (long long)VMF_KL_STATIC_MAX_N);
+  double* scratch = nullptr;
+  if (sum_out) {
+    int rc = kl_static_scratch(&scratch);
+    if (rc) return rc;
+  }
+  return kl_fwd_launch("vmf_kl_fwd_static", kappa, out, sum_out, scratch, alpha, n, variant, dtype,
+                       (hipStream_t)stream);
 }
 
 extern "C" int vmf_kl_bwd(const void* kappa, const void* gout, int64_t gout_stride, double gscale, void* dkappa,
