@@ -67,25 +67,58 @@ const char* vmf_last_error_string(void);
  * with stride 0 on broadcast dims.  odims and the four stride arrays are HOST arrays of length ndim
  * (1 <= ndim <= 8). */
 
+/* flags of the rsample entry points (vmf3_rsample_*, vmf_rsample_*) */
+#define VMF_FLAG_NORMALIZE_MU 1   /* general m: mu rows are raw (e.g. straight from a GEMM): sample around mu / ||mu||;
+                                     the backward pass returns the gradient with respect to the RAW rows */
+#define VMF_FLAG_SOFTPLUS_KAPPA 2 /* `scale` / `kappa` holds the raw output of the concentration head: the kernels use
+                                     kappa = softplus(raw) + 1 (model/spherical_vae.py:70, model/torus_vae.py:103-104,
+                                     CNN_experiment/circular_VAE.py:50; torch's softplus, beta 1, threshold 20) and
+                                     the backward pass returns the gradient with respect to the RAW values */
+
 /* Replaces VonMisesFisher3D.__init__'s normalisation and .rsample (sampler/von_mises_fisher.py:30, 50-86):
  *   l = loc/(||loc||+1e-5);  w = 1 + logsumexp(log u, log(1-u) - 2k)/k;  v = normalise(eps - <eps,l> l);
  *   z = w l + sqrt(clamp(1-w^2, 1e-10, 1)) v.
  * u / eps may be null: then u[i] comes from Philox(index i, slot 0) and eps row j from Philox(index j,
- * slot 1) (Box-Muller).  w_out (nullable) receives w, indexed like u. */
+ * slot 1) (Box-Muller).  w_out (nullable) receives w, indexed like u; kappa_out (nullable) receives the kappa the
+ * kernel used, indexed like scale (of interest with VMF_FLAG_SOFTPLUS_KAPPA: the KL term needs it).
+ * fp32 calls evaluate log / exp / sqrt / 1/x with the 1-ulp hardware instructions, fp64 calls with the accurate
+ * library.  Two broadcast shapes have kernels of their own (vmf3_broadcast_kind tells which a call is): every operand
+ * indexed by the output row ((B, 3) loc with (B,) scale), and the outer product u / scale x loc / eps that a (B, 1)
+ * scale produces ((B, B, 3), model/spherical_vae.py:81-83). */
 int vmf3_rsample_fwd(const void* loc, const void* scale, const void* u, const void* eps, void* z, void* w_out,
-                     int ndim, const int64_t* odims, const int64_t* w_str, const int64_t* k_str,
-                     const int64_t* l_str, const int64_t* e_str, int dtype, uint64_t seed, uint64_t offset,
+                     void* kappa_out, int ndim, const int64_t* odims, const int64_t* w_str, const int64_t* k_str,
+                     const int64_t* l_str, const int64_t* e_str, int flags, int dtype, uint64_t seed, uint64_t offset,
                      const uint64_t* offset_dev, vmf_stream_t stream);
+
+/* 1: every operand is indexed by the output row; 2: outer product (*n_i = elements of u / scale, *n_j = rows of
+ * loc / eps; the result is (n_i, n_j, 3)); 0: any other broadcast.  Host only, touches no GPU.  n_i / n_j nullable. */
+int vmf3_broadcast_kind(int ndim, const int64_t* odims, const int64_t* w_str, const int64_t* k_str,
+                        const int64_t* l_str, const int64_t* e_str, int64_t* n_i, int64_t* n_j);
 
 /* Backward of the above (what autograd derives from sampler/von_mises_fisher.py:30, 58-84):
  * dloc (n_loc rows of 3) and dscale (n_scale) receive J^T grad_z.  They are overwritten.  When several
  * output rows share a loc row or a scale element the partial results are combined with float atomics --
  * unless n_loc == n_scale == number of output rows: then row o of dloc / dscale receives output row o's
- * contribution and the caller reduces over the rows that share an operand (reproducible run to run). */
+ * contribution and the caller reduces over the rows that share an operand (reproducible run to run).
+ * grad_kappa (nullable, indexed like scale): gradient with respect to the kappa_out of the forward call, added to
+ * dscale before the softplus chain rule; accepted for broadcast kind 1 only.  Kind 2 is better served by
+ * vmf3_rsample_bwd_outer. */
 int vmf3_rsample_bwd(const void* loc, const void* scale, const void* u, const void* eps, const void* grad_z,
-                     void* dloc, void* dscale, int64_t n_loc, int64_t n_scale, int ndim, const int64_t* odims,
-                     const int64_t* w_str, const int64_t* k_str, const int64_t* l_str, const int64_t* e_str,
-                     int dtype, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream);
+                     const void* grad_kappa, void* dloc, void* dscale, int64_t n_loc, int64_t n_scale, int ndim,
+                     const int64_t* odims, const int64_t* w_str, const int64_t* k_str, const int64_t* l_str,
+                     const int64_t* e_str, int flags, int dtype, uint64_t seed, uint64_t offset,
+                     const uint64_t* offset_dev, vmf_stream_t stream);
+
+/* Backward of the outer-product shape (broadcast kind 2: grad_z is (n_i, n_j, 3), u / scale have n_i elements,
+ * loc / eps n_j rows) in one pass over grad_z: dloc (n_j, 3) = sum over i, dscale (n_i) = sum over j, both reduced
+ * inside the library in a fixed order (same bits every run, no (n_i, n_j, 3) temporary).  workspace: device memory
+ * of at least the byte count vmf3_rsample_bwd_outer_workspace reports (about 3.4 % of grad_z for large shapes),
+ * 16-byte aligned, contents irrelevant before and after the call.  grad_kappa as above. */
+int vmf3_rsample_bwd_outer_workspace(int64_t n_i, int64_t n_j, int dtype, int64_t* bytes_out);
+int vmf3_rsample_bwd_outer(const void* loc, const void* scale, const void* u, const void* eps, const void* grad_z,
+                           const void* grad_kappa, void* dloc, void* dscale, int64_t n_i, int64_t n_j, void* workspace,
+                           int64_t workspace_bytes, int flags, int dtype, uint64_t seed, uint64_t offset,
+                           const uint64_t* offset_dev, vmf_stream_t stream);
 
 /* _sample_w3 alone  sampler/von_mises_fisher.py:50-64: w[i] = 1 + logsumexp([log u_i, log(1-u_i) - 2k]) / k with
  * k = scale[i mod n_scale] (u, w have shape sample_shape + scale.shape, n elements); u null: Philox(index i, slot 0),
@@ -162,9 +195,7 @@ int vmf_kl_bwd(const void* kappa, const void* gout, int64_t gout_stride, double 
  * The accepted proposal index (first accepted, or the last one tried when none is) goes to accept_idx.
  * Outputs w_out (n), omw_out (n; 1 - w computed without cancellation, what the backward wants),
  * accept_idx (n, int32), logp_out (n; log p(z) fused) are nullable. */
-/* flags of vmf_rsample_fwd / vmf_rsample_bwd */
-#define VMF_FLAG_NORMALIZE_MU 1 /* mu rows are raw (e.g. straight from a GEMM): sample around mu / ||mu||; the
-                                  backward pass returns the gradient with respect to the RAW rows */
+/* flags: VMF_FLAG_NORMALIZE_MU, VMF_FLAG_SOFTPLUS_KAPPA (defined with vmf3_rsample_fwd above) */
 int vmf_rsample_fwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, void* z, void* w_out,
                     void* omw_out, int32_t* accept_idx, void* logp_out, int64_t n, int m, const void* prop_e, const void* prop_u,
                     int n_prop, const void* gauss, int max_prop, uint64_t row0, uint64_t seed, uint64_t offset,

@@ -14,20 +14,27 @@ _DEFAULT = os.path.join(_HERE, "libvmf_hip.so")
 
 VMF_F32, VMF_F64 = 0, 1
 FLAG_NORMALIZE_MU = 1
+FLAG_SOFTPLUS_KAPPA = 2
+KIND_GENERAL, KIND_ROWS, KIND_OUTER = 0, 1, 2
 KL_SPHERICAL_PIECEWISE, KL_TORUS_RAW, KL_CIRCULAR_EPS, KL_S1_I0I1, KL_STABLE_M3, KL_STABLE_M2 = range(6)
 KL_WORKSPACE_DOUBLES = 1024
 KL_STATIC_MAX_N = 1 << 30
 ELBO_WORKSPACE_DOUBLES = 2048
 LATENT_S1, LATENT_S2, LATENT_T2 = range(3)
 
+# (the module object `C` is re-used by callers for byref / c_int64)
 _P, _I64, _U64, _I, _D = C.c_void_p, C.c_int64, C.c_uint64, C.c_int, C.c_double
 _I64P = C.POINTER(C.c_int64)
 
 # name -> argtypes; every function returns int except the two noted below
 _PROTOS = {
-    "vmf3_rsample_fwd": [_P, _P, _P, _P, _P, _P, _I, _I64P, _I64P, _I64P, _I64P, _I64P, _I, _U64, _U64, _P, _P],
-    "vmf3_rsample_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I64P, _I64P, _I64P, _I64P, _I64P, _I, _U64,
-                         _U64, _P, _P],
+    "vmf3_rsample_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I64P, _I64P, _I64P, _I64P, _I64P, _I, _I, _U64, _U64, _P,
+                         _P],
+    "vmf3_broadcast_kind": [_I, _I64P, _I64P, _I64P, _I64P, _I64P, _I64P, _I64P],
+    "vmf3_rsample_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I64P, _I64P, _I64P, _I64P, _I64P, _I, _I,
+                         _U64, _U64, _P, _P],
+    "vmf3_rsample_bwd_outer_workspace": [_I64, _I64, _I, _I64P],
+    "vmf3_rsample_bwd_outer": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _I64, _I, _I, _U64, _U64, _P, _P],
     "vmf3_sample_w_fwd": [_P, _P, _P, _I64, _I64, _I, _U64, _U64, _P, _P],
     "vmf3_sample_w_bwd": [_P, _P, _P, _P, _I64, _I64, _I, _U64, _U64, _P, _P],
     "vmf3_log_prob_ref": [_P, _P, _P, _P, _P, _I64, _I, _P],

@@ -149,6 +149,7 @@ template <> struct M<float> {
   static VMF_HD float abs(float x) { return ::fabsf(x); }
   static VMF_HD float log1p(float x) { return ::log1pf(x); }
   static VMF_HD float expm1(float x) { return ::expm1f(x); }
+  static VMF_HD float div(float a, float b) { return a / b; }
   static __device__ __forceinline__ void sincospi2(float u, float* s, float* c) { ::sincospif(2.0f * u, s, c); }
 };
 template <> struct M<double> {
@@ -160,6 +161,7 @@ template <> struct M<double> {
   static VMF_HD double abs(double x) { return ::fabs(x); }
   static VMF_HD double log1p(double x) { return ::log1p(x); }
   static VMF_HD double expm1(double x) { return ::expm1(x); }
+  static VMF_HD double div(double a, double b) { return a / b; }
   static __device__ __forceinline__ void sincospi2(double u, double* s, double* c) { ::sincospi(2.0 * u, s, c); }
 };
 
@@ -206,6 +208,26 @@ VMF_HD float fast_rsqrt(float x) {
   return 1.0f / ::sqrtf(x);
 #endif
 }
+
+VMF_HD float fast_sqrt(float x) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __builtin_amdgcn_sqrtf(x);
+#else
+  return ::sqrtf(x);
+#endif
+}
+
+// Single-precision math policy with the interface of M<float>, built on the 1-ulp hardware instructions: what the fp32
+// m = 3 kernels run (the accurate M<float> costs 20-30 instructions per log / exp / division, several times the rest of
+// a row's arithmetic).  e^x needs no split product here: its arguments are differences of logarithms, at most a few
+// tens in magnitude where the result matters.
+struct MFast {
+  static VMF_HD float log(float x) { return fast_log(x); }
+  static VMF_HD float exp(float x) { return fast_exp2(1.44269504088896340736f * x); }
+  static VMF_HD float sqrt(float x) { return fast_sqrt(x); }
+  static VMF_HD float abs(float x) { return ::fabsf(x); }
+  static VMF_HD float div(float a, float b) { return a * fast_rcp(b); }
+};
 
 // ---- hot-path math: hardware transcendentals for float, the accurate library for double --------------------
 // v_log_f32 / v_exp_f32 / v_sqrt_f32 / v_rsq_f32 / v_rcp_f32 are 1-ulp single instructions; v_sin_f32 / v_cos_f32
@@ -412,3 +434,31 @@ template <typename T>
 struct alignas(sizeof(T) * 4 > 16 ? 16 : sizeof(T) * 4) Vec4 {
   T v[4];
 };
+
+// ---- streaming stores and wave-private LDS hand-offs (shared by the m = 3 and general-m kernels) --------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// cache modifiers of streaming stores (measured on the general-m kernel, 2^24 x 64 rows: plain 1.000, nt 0.989,
+// sc0 sc1 nt 0.967 with an nt load)
+#ifndef VMF_ST_MOD
+#define VMF_ST_MOD "sc0 sc1 nt"
+#endif
+// Streaming store of one 128-bit piece of z.  Issued from inline asm because the compiler loses the non-temporal
+// mark of __builtin_nontemporal_store in the one-pass instantiations (their store came out without `nt`; the
+// multi-pass ones kept it).  The s_nop covers the wait states a VALU write to the data registers needs after a store
+// wider than 64 bits, which the compiler's hazard pass cannot see inside an asm block.  The memory counter only ever
+// reads higher than the compiler assumes because of this store, so its own waits stay sufficient.
+__device__ __forceinline__ void store_nt(f32x4 v, float* ptr) {
+  asm volatile("global_store_dwordx4 %0, %1, off " VMF_ST_MOD "\n\ts_nop 1" : : "v"(ptr), "v"(v) : "memory");
+}
+
+// The w / 1-w^2 slabs are private to a wave: producer and consumer lanes belong to the same wave, whose LDS
+// operations execute in program order.  All that is needed between the phases is that the compiler keeps that order
+// and that outstanding LDS operations have retired; no workgroup barrier, and no wait on global memory.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+

@@ -1,14 +1,15 @@
 // vmf3.hip -- VonMisesFisher3D on gfx950: fused normalise + inverse-CDF w + tangent + combine, its backward,
 // the m = 3 log_prob / mean, and the library's error plumbing.
 //
-// One thread owns one OUTPUT row (3 values).  The reference launches ~25 elementwise kernels and
-// materialises every intermediate (sampler/von_mises_fisher.py:30, 50-86); here each row is 28 bytes of
-// algorithmic traffic in elementwise layout (loc 12 + scale 4 + z 12 in fp32) and everything else stays in
-// registers.  Broadcast results (the (B,1)-scale quirk that yields (B,B,3)) re-derive the per-i and per-j
-// pieces in every thread: the arithmetic is ~100 flops per 12 written bytes, far below the HBM time.
+// The reference launches ~25 elementwise kernels and materialises every intermediate
+// (sampler/von_mises_fisher.py:30, 50-86).  Here the entry points classify the broadcast of a call: the two shapes
+// the reference's models produce -- one row per (loc, scale) pair, and the (B, 1)-scale outer product (B, B, 3) --
+// have kernels of their own in vmf3_fast.hip; any other broadcast (sample shapes in front of shared parameters ...)
+// takes the thread-per-output-row kernels below.
 #include <stdarg.h>
 #include <stdio.h>
 
+#include "vmf3_fast.h"
 #include "vmf_math.h"
 
 // ---- error plumbing ---------------------------------------------------------------------------
@@ -99,76 +100,104 @@ static int make_bcast(Bcast* bc, int64_t* n_out, int ndim, const int64_t* odims,
   return VMF_OK;
 }
 
-// noise for one row: u from Philox(index wi, slot 0), eps row from Philox(index ei, slot 1)
-template <typename T>
-__device__ __forceinline__ T v3_draw_u(const T* u, int64_t wi, PhiloxKey key) {
-  if (u) return u[wi];
-  return u01<T>(philox4x32_10((uint64_t)wi, 0u, key).x);
-}
-template <typename T>
-__device__ __forceinline__ void v3_draw_eps(const T* eps, int64_t ei, PhiloxKey key, T e[3]) {
-  if (eps) {
-    e[0] = eps[3 * ei]; e[1] = eps[3 * ei + 1]; e[2] = eps[3 * ei + 2];
-    return;
+// What shape a call has once size-1 dims are dropped and dims that walk all four operands contiguously are merged:
+// ROWS (every operand indexed by the output row), OUTER (u / scale indexed by the first dim, loc / eps by the second:
+// the (B, 1)-scale broadcast) or anything else (sample shapes in front of shared parameters ...).
+enum { V3_KIND_GENERAL = 0, V3_KIND_ROWS = 1, V3_KIND_OUTER = 2 };
+static int bcast_kind(const Bcast& bc, int64_t* n_i, int64_t* n_j) {
+  int64_t d[8], w[8], k[8], l[8], e[8];
+  int nd = 0;
+  for (int x = 0; x < bc.ndim; ++x) {
+    if (bc.odims[x] == 1) continue;
+    d[nd] = bc.odims[x]; w[nd] = bc.w_str[x]; k[nd] = bc.k_str[x]; l[nd] = bc.l_str[x]; e[nd] = bc.e_str[x];
+    ++nd;
   }
-  T n4[4];
-  philox_normal4<T>((uint64_t)ei, 1u, key, n4);
-  e[0] = n4[0]; e[1] = n4[1]; e[2] = n4[2];
+  for (int x = nd - 2; x >= 0; --x) {  // merge dim x+1 into dim x where all four operands allow it
+    const int64_t m = d[x + 1];
+    if (w[x] == w[x + 1] * m && k[x] == k[x + 1] * m && l[x] == l[x + 1] * m && e[x] == e[x + 1] * m) {
+      d[x] *= m; w[x] = w[x + 1]; k[x] = k[x + 1]; l[x] = l[x + 1]; e[x] = e[x + 1];
+      for (int y = x + 1; y < nd - 1; ++y) { d[y] = d[y + 1]; w[y] = w[y + 1]; k[y] = k[y + 1]; l[y] = l[y + 1]; e[y] = e[y + 1]; }
+      --nd;
+    }
+  }
+  if (nd == 0) { *n_i = 1; *n_j = 1; return V3_KIND_ROWS; }
+  if (nd == 1 && w[0] == 1 && k[0] == 1 && l[0] == 1 && e[0] == 1) { *n_i = d[0]; *n_j = d[0]; return V3_KIND_ROWS; }
+  if (nd == 2 && w[0] == 1 && k[0] == 1 && l[0] == 0 && e[0] == 0 && w[1] == 0 && k[1] == 0 && l[1] == 1 && e[1] == 1) {
+    *n_i = d[0]; *n_j = d[1];
+    return V3_KIND_OUTER;
+  }
+  *n_i = *n_j = 0;
+  return V3_KIND_GENERAL;
 }
 
-template <typename T>
+extern "C" int vmf3_broadcast_kind(int ndim, const int64_t* odims, const int64_t* w_str, const int64_t* k_str,
+                                   const int64_t* l_str, const int64_t* e_str, int64_t* n_i, int64_t* n_j) {
+  Bcast bc;
+  int64_t n_out = 0, a = 0, b = 0;
+  int rc = make_bcast(&bc, &n_out, ndim, odims, w_str, k_str, l_str, e_str);
+  if (rc) return rc;
+  const int kind = n_out == 0 ? V3_KIND_GENERAL : bcast_kind(bc, &a, &b);
+  if (n_i) *n_i = a;
+  if (n_j) *n_j = b;
+  return kind;
+}
+
+// The general kernel: one thread per output row, operands found through the broadcast descriptor.
+template <typename T, typename MP>
 __global__ __launch_bounds__(256) void vmf3_fwd_kernel(const T* __restrict__ loc, const T* __restrict__ scale,
                                                        const T* __restrict__ u, const T* __restrict__ eps,
-                                                       T* __restrict__ z, T* __restrict__ w_out, Bcast bc,
-                                                       int64_t n_out, PhiloxArg ka) {
+                                                       T* __restrict__ z, T* __restrict__ w_out,
+                                                       T* __restrict__ kappa_out, Bcast bc, int64_t n_out,
+                                                       int softplus, PhiloxArg ka) {
   const PhiloxKey key = philox_resolve(ka);
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += stride) {
     int64_t wi, ki, li, ei;
     unravel(bc, o, &wi, &ki, &li, &ei);
     T r[3] = {loc[3 * li], loc[3 * li + 1], loc[3 * li + 2]};
-    T k = scale[ki];
+    T sig;
+    const T k = softplus ? v3_softplus_kappa<T, MP>(scale[ki], &sig) : scale[ki];
     T uu = v3_draw_u<T>(u, wi, key);
     T e[3];
     v3_draw_eps<T>(eps, ei, key, e);
     T l[3], t[3], v[3], n, p, s, L, x2;
     bool inside;
-    v3_normalise_loc<T>(r, l, &n);
-    T w = v3_w<T>(uu, k, &L, &x2);
-    v3_tangent<T>(e, l, t, v, &p, &s);
-    T f = v3_factor<T>(w, &inside);
+    v3_normalise_loc<T, MP>(r, l, &n);
+    T w = v3_w<T, MP>(uu, k, &L, &x2);
+    v3_tangent<T, MP>(e, l, t, v, &p, &s);
+    T f = v3_factor<T, MP>(w, &inside);
     z[3 * o] = w * l[0] + f * v[0];
     z[3 * o + 1] = w * l[1] + f * v[1];
     z[3 * o + 2] = w * l[2] + f * v[2];
     if (w_out) w_out[wi] = w;
+    if (kappa_out) kappa_out[ki] = k;  // rows that share a scale element write the same value
   }
 }
 
-template <typename T>
+template <typename T, typename MP>
 __global__ __launch_bounds__(256) void vmf3_bwd_kernel(const T* __restrict__ loc, const T* __restrict__ scale,
                                                        const T* __restrict__ u, const T* __restrict__ eps,
                                                        const T* __restrict__ gz, T* __restrict__ dloc,
                                                        T* __restrict__ dscale, Bcast bc, int64_t n_out,
-                                                       int per_row, PhiloxArg ka) {
+                                                       int per_row, int softplus, PhiloxArg ka) {
   const PhiloxKey key = philox_resolve(ka);
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += stride) {
     int64_t wi, ki, li, ei;
     unravel(bc, o, &wi, &ki, &li, &ei);
     T r[3] = {loc[3 * li], loc[3 * li + 1], loc[3 * li + 2]};
-    T k = scale[ki];
+    T sig = (T)1;
+    const T k = softplus ? v3_softplus_kappa<T, MP>(scale[ki], &sig) : scale[ki];
     T uu = v3_draw_u<T>(u, wi, key);
     T e[3];
     v3_draw_eps<T>(eps, ei, key, e);
     T g[3] = {gz[3 * o], gz[3 * o + 1], gz[3 * o + 2]};
     T dr[3], dk;
-    v3_backward_row<T>(r, k, uu, e, g, dr, &dk);
+    v3_backward_row<T, MP>(r, k, uu, e, g, dr, &dk);
+    dk *= sig;
     if (per_row) {  // one gradient row per output row; the caller sums the rows that share an operand
       dloc[3 * o] = dr[0]; dloc[3 * o + 1] = dr[1]; dloc[3 * o + 2] = dr[2];
       dscale[o] = dk;
-    } else if (bc.identity) {
-      dloc[3 * li] = dr[0]; dloc[3 * li + 1] = dr[1]; dloc[3 * li + 2] = dr[2];
-      dscale[ki] = dk;
     } else {
       atomicAdd(&dloc[3 * li], dr[0]);
       atomicAdd(&dloc[3 * li + 1], dr[1]);
@@ -178,63 +207,129 @@ __global__ __launch_bounds__(256) void vmf3_bwd_kernel(const T* __restrict__ loc
   }
 }
 
+static V3Call make_call(const void* loc, const void* scale, const void* u, const void* eps, int flags, int dtype,
+                        uint64_t seed, uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream) {
+  V3Call c = {};
+  c.loc = loc; c.scale = scale; c.u = u; c.eps = eps;
+  c.softplus = (flags & VMF_FLAG_SOFTPLUS_KAPPA) ? 1 : 0;
+  c.dtype = dtype;
+  c.ka = make_philox_arg(seed, offset, offset_dev);
+  c.stream = (hipStream_t)stream;
+  return c;
+}
+
 extern "C" int vmf3_rsample_fwd(const void* loc, const void* scale, const void* u, const void* eps, void* z,
-                                void* w_out, int ndim, const int64_t* odims, const int64_t* w_str,
-                                const int64_t* k_str, const int64_t* l_str, const int64_t* e_str, int dtype,
-                                uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
-                                vmf_stream_t stream) {
+                                void* w_out, void* kappa_out, int ndim, const int64_t* odims, const int64_t* w_str,
+                                const int64_t* k_str, const int64_t* l_str, const int64_t* e_str, int flags, int dtype,
+                                uint64_t seed, uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream) {
   Bcast bc;
   int64_t n_out = 0;
   int rc = make_bcast(&bc, &n_out, ndim, odims, w_str, k_str, l_str, e_str);
   if (rc) return rc;
+  VMF_REQUIRE(dtype == VMF_F32 || dtype == VMF_F64, VMF_ERR_DTYPE, "dtype %d is not VMF_F32/VMF_F64", dtype);
+  VMF_REQUIRE((flags & ~VMF_FLAG_SOFTPLUS_KAPPA) == 0, VMF_ERR_BAD_ARG, "vmf3_rsample_fwd: unknown flags %d", flags);
   if (n_out == 0) return VMF_OK;
   VMF_REQUIRE(loc && scale && z, VMF_ERR_BAD_ARG, "vmf3_rsample_fwd: null loc/scale/z");
-  PhiloxArg key = make_philox_arg(seed, offset, offset_dev);
-  int grid = vmf_grid_for(n_out, 256);
-  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(vmf3_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                               (const T*)loc, (const T*)scale, (const T*)u, (const T*)eps, (T*)z,
-                                               (T*)w_out, bc, n_out, key));
+  V3Call c = make_call(loc, scale, u, eps, flags, dtype, seed, offset, offset_dev, stream);
+  c.z = z; c.w_out = w_out; c.kappa_out = kappa_out;
+  int64_t n_i = 0, n_j = 0;
+  const int kind = bcast_kind(bc, &n_i, &n_j);
+  if (kind == V3_KIND_ROWS) {
+    rc = vmf3_fwd_rows(c, n_out);
+  } else if (kind == V3_KIND_OUTER) {
+    rc = vmf3_fwd_outer(c, n_i, n_j);
+  } else {
+    int grid = vmf_grid_for(n_out, 256);
+    if (dtype == VMF_F32)
+      hipLaunchKernelGGL((vmf3_fwd_kernel<float, MFast>), dim3(grid), dim3(256), 0, c.stream, (const float*)loc,
+                         (const float*)scale, (const float*)u, (const float*)eps, (float*)z, (float*)w_out,
+                         (float*)kappa_out, bc, n_out, c.softplus, c.ka);
+    else
+      hipLaunchKernelGGL((vmf3_fwd_kernel<double, M<double>>), dim3(grid), dim3(256), 0, c.stream, (const double*)loc,
+                         (const double*)scale, (const double*)u, (const double*)eps, (double*)z, (double*)w_out,
+                         (double*)kappa_out, bc, n_out, c.softplus, c.ka);
+  }
+  if (rc) return rc;
   return vmf_check_launch("vmf3_rsample_fwd");
 }
 
 extern "C" int vmf3_rsample_bwd(const void* loc, const void* scale, const void* u, const void* eps,
-                                const void* grad_z, void* dloc, void* dscale, int64_t n_loc, int64_t n_scale,
-                                int ndim, const int64_t* odims, const int64_t* w_str, const int64_t* k_str,
-                                const int64_t* l_str, const int64_t* e_str, int dtype, uint64_t seed,
-                                uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream) {
+                                const void* grad_z, const void* grad_kappa, void* dloc, void* dscale, int64_t n_loc,
+                                int64_t n_scale, int ndim, const int64_t* odims, const int64_t* w_str,
+                                const int64_t* k_str, const int64_t* l_str, const int64_t* e_str, int flags, int dtype,
+                                uint64_t seed, uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream) {
   Bcast bc;
   int64_t n_out = 0;
   int rc = make_bcast(&bc, &n_out, ndim, odims, w_str, k_str, l_str, e_str);
   if (rc) return rc;
   VMF_REQUIRE(dtype == VMF_F32 || dtype == VMF_F64, VMF_ERR_DTYPE, "dtype %d", dtype);
+  VMF_REQUIRE((flags & ~VMF_FLAG_SOFTPLUS_KAPPA) == 0, VMF_ERR_BAD_ARG, "vmf3_rsample_bwd: unknown flags %d", flags);
   VMF_REQUIRE(n_loc >= 0 && n_scale >= 0, VMF_ERR_BAD_ARG, "negative sizes");
   if (n_loc == 0 && n_scale == 0) return VMF_OK;
   VMF_REQUIRE(loc && scale && grad_z && dloc && dscale, VMF_ERR_BAD_ARG, "vmf3_rsample_bwd: null pointer");
+  V3Call c = make_call(loc, scale, u, eps, flags, dtype, seed, offset, offset_dev, stream);
+  c.gz = grad_z; c.gkappa = grad_kappa; c.dloc = dloc; c.dscale = dscale;
+  int64_t n_i = 0, n_j = 0;
+  const int kind = n_out ? bcast_kind(bc, &n_i, &n_j) : V3_KIND_GENERAL;
+  if (kind == V3_KIND_ROWS && n_loc == n_out && n_scale == n_out) {
+    rc = vmf3_bwd_rows(c, n_out);
+    if (rc) return rc;
+    return vmf_check_launch("vmf3_rsample_bwd");
+  }
+  VMF_REQUIRE(!grad_kappa, VMF_ERR_UNSUPPORTED,
+              "vmf3_rsample_bwd: grad_kappa is taken by the row-per-row shape (and by vmf3_rsample_bwd_outer) only");
   size_t es = dtype == VMF_F32 ? 4 : 8;
-  // identity also requires that the outputs are exactly as large as the result
-  if (bc.identity && !(n_loc == n_out && n_scale == n_out)) bc.identity = 0;
   // Outputs as large as the result although operands are shared: per-row mode.  Row o of dloc / dscale receives the
   // contribution of output row o and the caller adds up the rows that share a loc row / scale element in an order
   // of its choosing -- the run-to-run reproducible alternative to the float atomics below.
-  const int per_row = !bc.identity && n_loc == n_out && n_scale == n_out;
-  if (!bc.identity && !per_row) {
-    if (hipMemsetAsync(dloc, 0, es * 3 * (size_t)n_loc, (hipStream_t)stream) != hipSuccess ||
-        hipMemsetAsync(dscale, 0, es * (size_t)n_scale, (hipStream_t)stream) != hipSuccess)
+  const int per_row = n_loc == n_out && n_scale == n_out;
+  if (!per_row) {
+    if (hipMemsetAsync(dloc, 0, es * 3 * (size_t)n_loc, c.stream) != hipSuccess ||
+        hipMemsetAsync(dscale, 0, es * (size_t)n_scale, c.stream) != hipSuccess)
       return vmf_check_launch("vmf3_rsample_bwd memset");
   }
   if (n_out == 0) return VMF_OK;
-  PhiloxArg key = make_philox_arg(seed, offset, offset_dev);
   int grid = vmf_grid_for(n_out, 256);
-  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(vmf3_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                               (const T*)loc, (const T*)scale, (const T*)u, (const T*)eps,
-                                               (const T*)grad_z, (T*)dloc, (T*)dscale, bc, n_out, per_row,
-                                               key));
+  if (dtype == VMF_F32)
+    hipLaunchKernelGGL((vmf3_bwd_kernel<float, MFast>), dim3(grid), dim3(256), 0, c.stream, (const float*)loc,
+                       (const float*)scale, (const float*)u, (const float*)eps, (const float*)grad_z, (float*)dloc,
+                       (float*)dscale, bc, n_out, per_row, c.softplus, c.ka);
+  else
+    hipLaunchKernelGGL((vmf3_bwd_kernel<double, M<double>>), dim3(grid), dim3(256), 0, c.stream, (const double*)loc,
+                       (const double*)scale, (const double*)u, (const double*)eps, (const double*)grad_z,
+                       (double*)dloc, (double*)dscale, bc, n_out, per_row, c.softplus, c.ka);
   return vmf_check_launch("vmf3_rsample_bwd");
+}
+
+extern "C" int vmf3_rsample_bwd_outer_workspace(int64_t n_i, int64_t n_j, int dtype, int64_t* bytes_out) {
+  VMF_REQUIRE(n_i >= 0 && n_j >= 0 && bytes_out, VMF_ERR_BAD_ARG, "vmf3_rsample_bwd_outer_workspace: bad argument");
+  VMF_REQUIRE(dtype == VMF_F32 || dtype == VMF_F64, VMF_ERR_DTYPE, "dtype %d", dtype);
+  *bytes_out = vmf3_bwd_outer_workspace_bytes(n_i, n_j, dtype);
+  return VMF_OK;
+}
+
+extern "C" int vmf3_rsample_bwd_outer(const void* loc, const void* scale, const void* u, const void* eps,
+                                      const void* grad_z, const void* grad_kappa, void* dloc, void* dscale,
+                                      int64_t n_i, int64_t n_j, void* workspace, int64_t workspace_bytes, int flags,
+                                      int dtype, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                      vmf_stream_t stream) {
+  VMF_REQUIRE(n_i >= 0 && n_j >= 0, VMF_ERR_BAD_ARG, "vmf3_rsample_bwd_outer: negative size");
+  VMF_REQUIRE(dtype == VMF_F32 || dtype == VMF_F64, VMF_ERR_DTYPE, "dtype %d", dtype);
+  VMF_REQUIRE((flags & ~VMF_FLAG_SOFTPLUS_KAPPA) == 0, VMF_ERR_BAD_ARG, "vmf3_rsample_bwd_outer: unknown flags %d", flags);
+  if (n_i == 0 && n_j == 0) return VMF_OK;
+  VMF_REQUIRE(n_i > 0 && n_j > 0, VMF_ERR_UNSUPPORTED, "vmf3_rsample_bwd_outer: an empty dimension next to a non-empty "
+              "one (zero-fill the gradients instead)");
+  VMF_REQUIRE(loc && scale && grad_z && dloc && dscale, VMF_ERR_BAD_ARG, "vmf3_rsample_bwd_outer: null pointer");
+  V3Call c = make_call(loc, scale, u, eps, flags, dtype, seed, offset, offset_dev, stream);
+  c.gz = grad_z; c.gkappa = grad_kappa; c.dloc = dloc; c.dscale = dscale;
+  int rc = vmf3_bwd_outer(c, n_i, n_j, workspace, workspace_bytes);
+  if (rc) return rc;
+  return vmf_check_launch("vmf3_rsample_bwd_outer");
 }
 
 // ---- _sample_w3 alone (sampler/von_mises_fisher.py:50-64): w = 1 + logsumexp([log u, log(1-u) - 2k]) / k ----------
 // u has shape sample_shape + scale.shape, so element i pairs with scale[i mod n_scale].
-template <typename T, bool BWD>
+template <typename T, typename MP, bool BWD>
 __global__ __launch_bounds__(256) void vmf3_w_kernel(const T* __restrict__ scale, const T* __restrict__ u,
                                                      const T* __restrict__ gw, T* __restrict__ out, int64_t n,
                                                      int64_t n_scale, PhiloxArg ka) {
@@ -244,12 +339,12 @@ __global__ __launch_bounds__(256) void vmf3_w_kernel(const T* __restrict__ scale
     const T k = scale[i % n_scale];
     const T uu = v3_draw_u<T>(u, i, key);
     T L, x2;
-    const T w = v3_w<T>(uu, k, &L, &x2);
+    const T w = v3_w<T, MP>(uu, k, &L, &x2);
     if (!BWD) {
       out[i] = w;
     } else {  // d w / d k = -L / k^2 - 2 sigma / k, sigma = exp(x2 - L): per-element term, the caller sums over samples
-      const T sig = M<T>::exp(x2 - L);
-      out[i] = gw[i] * (-L / (k * k) - (T)2 * sig / k);
+      const T sig = MP::exp(x2 - L);
+      out[i] = gw[i] * (-MP::div(L, k * k) - (T)2 * MP::div(sig, k));
     }
   }
 }
@@ -263,9 +358,15 @@ extern "C" int vmf3_sample_w_fwd(const void* scale, const void* u, void* w, int6
   VMF_REQUIRE(scale && w, VMF_ERR_BAD_ARG, "vmf3_sample_w_fwd: null pointer");
   PhiloxArg key = make_philox_arg(seed, offset, offset_dev);
   int grid = vmf_grid_for(n, 256);
-  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((vmf3_w_kernel<T, false>), dim3(grid), dim3(256), 0,
-                                               (hipStream_t)stream, (const T*)scale, (const T*)u, (const T*)nullptr,
-                                               (T*)w, n, n_scale, key));
+  // fp32 runs the arithmetic of the fp32 rsample kernels (hardware transcendentals), so both give the same w
+  if (dtype == VMF_F32)
+    hipLaunchKernelGGL((vmf3_w_kernel<float, MFast, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)scale, (const float*)u, (const float*)nullptr, (float*)w, n, n_scale, key);
+  else if (dtype == VMF_F64)
+    hipLaunchKernelGGL((vmf3_w_kernel<double, M<double>, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)scale, (const double*)u, (const double*)nullptr, (double*)w, n, n_scale, key);
+  else
+    VMF_REQUIRE(false, VMF_ERR_DTYPE, "dtype %d is not VMF_F32/VMF_F64", dtype);
   return vmf_check_launch("vmf3_sample_w_fwd");
 }
 
@@ -278,9 +379,15 @@ extern "C" int vmf3_sample_w_bwd(const void* scale, const void* u, const void* g
   VMF_REQUIRE(scale && grad_w && dscale_rows, VMF_ERR_BAD_ARG, "vmf3_sample_w_bwd: null pointer");
   PhiloxArg key = make_philox_arg(seed, offset, offset_dev);
   int grid = vmf_grid_for(n, 256);
-  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((vmf3_w_kernel<T, true>), dim3(grid), dim3(256), 0,
-                                               (hipStream_t)stream, (const T*)scale, (const T*)u, (const T*)grad_w,
-                                               (T*)dscale_rows, n, n_scale, key));
+  if (dtype == VMF_F32)
+    hipLaunchKernelGGL((vmf3_w_kernel<float, MFast, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)scale, (const float*)u, (const float*)grad_w, (float*)dscale_rows, n, n_scale, key);
+  else if (dtype == VMF_F64)
+    hipLaunchKernelGGL((vmf3_w_kernel<double, M<double>, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)scale, (const double*)u, (const double*)grad_w, (double*)dscale_rows, n, n_scale,
+                       key);
+  else
+    VMF_REQUIRE(false, VMF_ERR_DTYPE, "dtype %d is not VMF_F32/VMF_F64", dtype);
   return vmf_check_launch("vmf3_sample_w_bwd");
 }
 

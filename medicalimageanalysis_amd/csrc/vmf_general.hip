@@ -171,40 +171,17 @@ struct FwdParams {
 // head would also wait for the store issued just before it -- the store's whole round trip, every step.  Rules that
 // keep this correct: the destination is touched by nothing between prefetch_issue() and prefetch_wait(); the wait
 // names the destination as an in/out operand so every use is ordered after it; vmcnt(0) over-waits at worst.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 // cache modifiers of the streaming kernel's mu load and z store.  A/B in one process on 2^24 x 64 rows (plain load +
 // plain store = 1.000): nt store 0.989, nt load + nt store 0.974, nt load + system-scope nt store 0.967; scope bits
 // without nt 0.985.  Every byte is touched once, so nothing is worth keeping in L2.
 #ifndef VMF_LD_MOD
 #define VMF_LD_MOD "nt"
 #endif
-#ifndef VMF_ST_MOD
-#define VMF_ST_MOD "sc0 sc1 nt"
-#endif
 __device__ __forceinline__ void prefetch_issue(f32x4& dst, const float* ptr) {
   asm volatile("global_load_dwordx4 %0, %1, off " VMF_LD_MOD : "=&v"(dst) : "v"(ptr) : "memory");
 }
 __device__ __forceinline__ void prefetch_wait(f32x4& dst) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(dst) : : "memory");
-}
-
-// Streaming store of one 128-bit piece of z.  Issued from inline asm because the compiler loses the non-temporal
-// mark of __builtin_nontemporal_store in the one-pass instantiations (their store came out without `nt`; the
-// multi-pass ones kept it).  The s_nop covers the wait states a VALU write to the data registers needs after a store
-// wider than 64 bits, which the compiler's hazard pass cannot see inside an asm block.  The memory counter only ever
-// reads higher than the compiler assumes because of this store, so its own waits stay sufficient.
-__device__ __forceinline__ void store_nt(f32x4 v, float* ptr) {
-  asm volatile("global_store_dwordx4 %0, %1, off " VMF_ST_MOD "\n\ts_nop 1" : : "v"(ptr), "v"(v) : "memory");
-}
-
-// The w / 1-w^2 slabs are private to a wave: producer and consumer lanes belong to the same wave, whose LDS
-// operations execute in program order.  All that is needed between the phases is that the compiler keeps that order
-// and that outstanding LDS operations have retired; no workgroup barrier, and no wait on global memory.
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 // Second launch bound = waves per SIMD: the one-pass fp32 streaming shapes (m <= 256) fit 8 waves (<= 64 VGPRs)

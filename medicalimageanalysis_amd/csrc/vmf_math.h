@@ -4,77 +4,129 @@
 #include "bessel_dev.h"
 #include "common.h"
 
+// MP is the math policy of the call: M<T> (accurate library functions, IEEE division) or, for fp32 kernels, MFast
+// (hardware log2 / exp2 / sqrt / reciprocal).
+
 // sampler/von_mises_fisher.py:30   l = loc / (||loc|| + 1e-5)
-template <typename T>
+template <typename T, typename MP = M<T>>
 VMF_HD void v3_normalise_loc(const T r[3], T l[3], T* n_out) {
-  T n = M<T>::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  T n = MP::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
   T den = n + (T)1e-5;
-  l[0] = r[0] / den; l[1] = r[1] / den; l[2] = r[2] / den;
+  l[0] = MP::div(r[0], den); l[1] = MP::div(r[1], den); l[2] = MP::div(r[2], den);
   *n_out = n;
 }
 
 // sampler/von_mises_fisher.py:58-63   w = 1 + logsumexp([log u, log(1-u) - 2k]) / k
 // (torch.logsumexp: log(sum(exp(x - max))) + max, an infinite max replaced by 0)
-template <typename T>
+template <typename T, typename MP = M<T>>
 VMF_HD T v3_w(T u, T k, T* L_out, T* x2_out) {
-  T x1 = M<T>::log(u);
-  T x2 = M<T>::log((T)1 - u) - (T)2 * k;
+  T x1 = MP::log(u);
+  T x2 = MP::log((T)1 - u) - (T)2 * k;
   T mx = x1 > x2 ? x1 : x2;
   if (x1 != x1 || x2 != x2) mx = x1 + x2;  // NaN
   T mxs = (mx == (T)INFINITY || mx == (T)-INFINITY) ? (T)0 : mx;
-  T L = M<T>::log(M<T>::exp(x1 - mxs) + M<T>::exp(x2 - mxs)) + mxs;
+  T L = MP::log(MP::exp(x1 - mxs) + MP::exp(x2 - mxs)) + mxs;
   *L_out = L;
   *x2_out = x2;
-  return (T)1 + L / k;
+  return (T)1 + MP::div(L, k);
 }
 
 // sampler/von_mises_fisher.py:77-79
-template <typename T>
+template <typename T, typename MP = M<T>>
 VMF_HD void v3_tangent(const T eps[3], const T l[3], T t[3], T v[3], T* p_out, T* s_out) {
   T p = eps[0] * l[0] + eps[1] * l[1] + eps[2] * l[2];
   t[0] = eps[0] - p * l[0]; t[1] = eps[1] - p * l[1]; t[2] = eps[2] - p * l[2];
-  T s = M<T>::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+  T s = MP::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
   T den = s + (T)1e-8;
-  v[0] = t[0] / den; v[1] = t[1] / den; v[2] = t[2] / den;
+  v[0] = MP::div(t[0], den); v[1] = MP::div(t[1], den); v[2] = MP::div(t[2], den);
   *p_out = p;
   *s_out = s;
 }
 
 // sampler/von_mises_fisher.py:83   sqrt(clamp(1 - w^2, 1e-10, 1))
-template <typename T>
+template <typename T, typename MP = M<T>>
 VMF_HD T v3_factor(T w, bool* inside) {
   T c = (T)1 - w * w;
   *inside = (c >= (T)1e-10) && (c <= (T)1);
   if (c < (T)1e-10) c = (T)1e-10;
   if (c > (T)1) c = (T)1;
-  return M<T>::sqrt(c);
+  return MP::sqrt(c);
 }
 
-// Backward of one output row (what autograd derives from :30, :58-63, :77-84): given g = dL/dz row,
-// returns dL/dloc row contribution (dr) and dL/dscale contribution (dk).
-template <typename T>
+// kappa = softplus(raw) + 1, the head of every encoder (model/spherical_vae.py:70, model/torus_vae.py:103-104,
+// CNN_experiment/circular_VAE.py:50): torch's softplus with beta = 1 (log1p(exp x), the identity above its threshold
+// of 20).  *sig receives d kappa / d raw.
+template <typename T, typename MP = M<T>>
+VMF_HD T v3_softplus_kappa(T raw, T* sig) {
+  if (raw > (T)20) {
+    *sig = (T)1;
+    return raw + (T)1;
+  }
+  const T e = MP::exp(raw);
+  *sig = MP::div(e, (T)1 + e);
+  // log1p(e): the series where 1 + e would round the small term away
+  const T l1p = e < (T)1e-4 ? e * ((T)1 - e * ((T)0.5 - e * (T)(1.0 / 3.0))) : MP::log((T)1 + e);
+  return l1p + (T)1;
+}
+template <>
+VMF_HD double v3_softplus_kappa<double, M<double>>(double raw, double* sig) {
+  if (raw > 20.0) {
+    *sig = 1.0;
+    return raw + 1.0;
+  }
+  const double e = ::exp(raw);
+  *sig = e / (1.0 + e);
+  return ::log1p(e) + 1.0;
+}
+
+// The two halves of the backward pass (what autograd derives from :30, :58-63, :77-84).
+// (1) through w: given gl = sum <g, l> and gv = sum <g, v> over the output rows that use this w,
+//     dL/dw = gl + gv * d sqrt(clamp(1 - w^2)) / dw, and dL/dk through w = 1 + L(k)/k.
+template <typename T, typename MP = M<T>>
+VMF_HD T v3_bwd_scale(T k, T u, T gl, T gv) {
+  T L, x2;
+  bool inside;
+  const T w = v3_w<T, MP>(u, k, &L, &x2);
+  const T f = v3_factor<T, MP>(w, &inside);
+  const T dw = gl + gv * (inside ? -MP::div(w, f) : (T)0);
+  const T sig = MP::exp(x2 - L);
+  return dw * (-MP::div(L, k * k) - (T)2 * MP::div(sig, k));
+}
+// (2) through the direction: given dl = sum w g and dv = sum f g over the output rows that use this (loc, eps) row,
+//     back through v = t / (|t| + 1e-8), t = eps - <eps, l> l and l = r / (|r| + 1e-5).
+template <typename T, typename MP = M<T>>
+VMF_HD void v3_bwd_loc(const T r[3], const T e[3], const T dl_in[3], const T dv[3], T dr[3]) {
+  T l[3], t[3], v[3], n, p, s, dt[3], dl[3];
+  v3_normalise_loc<T, MP>(r, l, &n);
+  v3_tangent<T, MP>(e, l, t, v, &p, &s);
+  const T sden = s + (T)1e-8;
+  const T tdv = t[0] * dv[0] + t[1] * dv[1] + t[2] * dv[2];
+  const T c2 = MP::div(tdv, s * sden * sden);
+  for (int c = 0; c < 3; ++c) dt[c] = MP::div(dv[c], sden) - t[c] * c2;
+  const T dtl = dt[0] * l[0] + dt[1] * l[1] + dt[2] * l[2];
+  for (int c = 0; c < 3; ++c) dl[c] = dl_in[c] - (dtl * e[c] + p * dt[c]);
+  const T nden = n + (T)1e-5;
+  const T rdl = r[0] * dl[0] + r[1] * dl[1] + r[2] * dl[2];
+  const T c3 = MP::div(rdl, n * nden * nden);
+  for (int c = 0; c < 3; ++c) dr[c] = MP::div(dl[c], nden) - r[c] * c3;
+}
+
+// Backward of one output row: given g = dL/dz row, returns the dL/dloc row contribution (dr) and the dL/dscale
+// contribution (dk).
+template <typename T, typename MP = M<T>>
 VMF_HD void v3_backward_row(const T r[3], T k, T u, const T e[3], const T g[3], T dr[3], T* dk_out) {
   T l[3], t[3], v[3], n, p, s, L, x2;
   bool inside;
-  v3_normalise_loc<T>(r, l, &n);
-  T w = v3_w<T>(u, k, &L, &x2);
-  v3_tangent<T>(e, l, t, v, &p, &s);
-  T f = v3_factor<T>(w, &inside);
-  T gl = g[0] * l[0] + g[1] * l[1] + g[2] * l[2];
-  T gv = g[0] * v[0] + g[1] * v[1] + g[2] * v[2];
-  T dw = gl + gv * (inside ? -w / f : (T)0);
-  T sig = M<T>::exp(x2 - L);
-  *dk_out = dw * (-L / (k * k) - (T)2 * sig / k);
-  T dv[3], dl[3], dt[3];
+  v3_normalise_loc<T, MP>(r, l, &n);
+  const T w = v3_w<T, MP>(u, k, &L, &x2);
+  v3_tangent<T, MP>(e, l, t, v, &p, &s);
+  const T f = v3_factor<T, MP>(w, &inside);
+  const T gl = g[0] * l[0] + g[1] * l[1] + g[2] * l[2];
+  const T gv = g[0] * v[0] + g[1] * v[1] + g[2] * v[2];
+  *dk_out = v3_bwd_scale<T, MP>(k, u, gl, gv);
+  T dv[3], dl[3];
   for (int c = 0; c < 3; ++c) { dv[c] = f * g[c]; dl[c] = w * g[c]; }
-  T sden = s + (T)1e-8;
-  T tdv = t[0] * dv[0] + t[1] * dv[1] + t[2] * dv[2];
-  for (int c = 0; c < 3; ++c) dt[c] = dv[c] / sden - t[c] * tdv / (s * sden * sden);
-  T dtl = dt[0] * l[0] + dt[1] * l[1] + dt[2] * l[2];
-  for (int c = 0; c < 3; ++c) dl[c] += -(dtl * e[c] + p * dt[c]);
-  T nden = n + (T)1e-5;
-  T rdl = r[0] * dl[0] + r[1] * dl[1] + r[2] * dl[2];
-  for (int c = 0; c < 3; ++c) dr[c] = dl[c] / nden - r[c] * rdl / (n * nden * nden);
+  v3_bwd_loc<T, MP>(r, e, dl, dv, dr);
 }
 
 // ---- KL variants: value and derivative per element -------------------------------------------------

@@ -3,6 +3,7 @@ import torch
 import torch.nn as nn
 
 from ..sampler.von_mises_fisher import VonMisesFisher3DLogProb as VonMisesFisher3D
+from ..sampler.von_mises_fisher import vmf3_rsample_from_heads
 from .. import kl as _kl
 from .. import losses as _losses
 
@@ -45,8 +46,10 @@ class CircularVAE(nn.Module):
         return self.decoder_net(z)
 
     def forward(self, x):
-        mu, logvar = self.encode(x)
-        z_sample, params = self.reparameterize(mu, logvar)
+        """CNN_experiment/circular_VAE.py:81-88; kappa = softplus(.) + 1 is evaluated inside the sampler kernel"""
+        h = self.encoder_net(x)
+        mu = self.fc_mu(h)
+        z_sample, logvar = vmf3_rsample_from_heads(mu, self.fc_logvar(h).squeeze(-1))
         x_recon = self.decode(z_sample)
         return z_sample, x_recon, (mu, logvar)
 

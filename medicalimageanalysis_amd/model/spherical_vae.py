@@ -9,7 +9,7 @@ import numpy as np  # noqa: F401  (the reference module exposes it)
 from ..sampler.spherical_uniform import *  # noqa: F401,F403
 from ..sampler.von_mises_fisher import *  # noqa: F401,F403
 from ..sampler.spherical_uniform import SphericalUniform
-from ..sampler.von_mises_fisher import VonMisesFisher3D
+from ..sampler.von_mises_fisher import VonMisesFisher3D, vmf3_rsample_from_heads
 from .. import kl as _kl
 from .. import losses as _losses
 
@@ -64,10 +64,17 @@ class SphericalVAE(nn.Module):
         return self.function_x_mu(h)
 
     def forward(self, x):
-        posteriori_params = self.encode(x)
-        z = self.reparemetrize(posteriori_params)
+        """encode -> reparemetrize -> decode with the values and the noise order of model/spherical_vae.py:103-117.  The
+        sampler kernel takes the RAW output of the concentration head and evaluates kappa = softplus(.) + 1 itself
+        (handing kappa back for the KL term), so the head's softplus / add passes and their backward launches are
+        gone; encode() and reparemetrize() remain for callers that use them separately."""
+        h = F.softplus(self.encoder_function(x), beta=self.sftbeta)
+        for layer in self.encoder_linear_layers:
+            h = F.softplus(layer(h), beta=self.sftbeta)
+        z_mu = self.function_z_mu(h)
+        z, z_kappa = vmf3_rsample_from_heads(z_mu, self.function_z_logvar(h))
         x_mu = self.decode(z)
-        return z, x_mu, posteriori_params
+        return z, x_mu, (z_mu, z_kappa)
 
     def _elbo(self, x, x_mu, posteriori_params):
         """gamma * mean((x - x_mu)^2) + beta * mean(KL)  (model/spherical_vae.py:119-138).  The distribution

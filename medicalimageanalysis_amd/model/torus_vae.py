@@ -8,7 +8,7 @@ import numpy as np  # noqa: F401
 from ..sampler.spherical_uniform import *  # noqa: F401,F403
 from ..sampler.von_mises_fisher import *  # noqa: F401,F403
 from ..sampler.spherical_uniform import SphericalUniform
-from ..sampler.von_mises_fisher import VonMisesFisher3D
+from ..sampler.von_mises_fisher import VonMisesFisher3D, vmf3_rsample_from_heads
 from .. import kl as _kl
 from .. import losses as _losses
 
@@ -74,10 +74,16 @@ class ToroidalVAE(nn.Module):
         return self.function_x_mu(h)
 
     def forward(self, x):
-        posteriori_params = self.encode(x)
-        z = self.reparemetrize(posteriori_params)
-        x_mu = self.decode(z)
-        return z, x_mu, posteriori_params
+        """encode -> reparemetrize -> decode (model/torus_vae.py:144-158); kappa = softplus(.) + 1 of both heads is
+        evaluated inside the sampler kernels (see SphericalVAE.forward).  Draw order: theta, then phi."""
+        h = F.softplus(self.encoder_function(x), beta=self.sftbeta)
+        for layer in self.encoder_linear_layers:
+            h = F.softplus(layer(h), beta=self.sftbeta)
+        z_theta_mu, z_phi_mu = self.function_z_theta_mu(h), self.function_z_phi_mu(h)
+        z_theta, z_theta_kappa = vmf3_rsample_from_heads(z_theta_mu, self.function_z_theta_logvar(h))
+        z_phi, z_phi_kappa = vmf3_rsample_from_heads(z_phi_mu, self.fucntion_z_phi_logvar(h))
+        z = self._build_torus(z_theta, z_phi)
+        return z, self.decode(z), (z_theta_mu, z_theta_kappa, z_phi_mu, z_phi_kappa)
 
     def _elbo(self, x, x_mu, posteriori_params):
         """called once per angle pair by the training loop (model/train.py:74-77)"""

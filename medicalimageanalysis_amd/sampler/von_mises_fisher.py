@@ -18,7 +18,7 @@ from .ive import ive
 from .spherical_uniform import HypersphericalUniform
 
 __all__ = ["math", "torch", "ive", "Distribution", "constraints", "VonMisesFisher3D", "VonMisesFisher3DLogProb",
-           "VonMisesFisher", "HypersphericalUniform"]
+           "VonMisesFisher", "HypersphericalUniform", "vmf3_rsample_from_heads"]
 
 _MAX_DIMS = 8
 
@@ -73,37 +73,76 @@ def _capture_safe(validate_args, t):
     return validate_args
 
 
+def _plan_kind(plan):
+    """(kind, n_i, n_j) of a broadcast plan as the library classifies it (vmf3_broadcast_kind; host only)"""
+    if "kind" not in plan:
+        ni, nj = _lib.C.c_int64(0), _lib.C.c_int64(0)
+        kind = _lib.lib().vmf3_broadcast_kind(
+            len(plan["odims"]), _lib.i64_array(plan["odims"]), _lib.i64_array(plan["w_str"]),
+            _lib.i64_array(plan["k_str"]), _lib.i64_array(plan["l_str"]), _lib.i64_array(plan["e_str"]),
+            _lib.C.byref(ni), _lib.C.byref(nj))
+        if kind < 0:
+            _lib.check(kind, "vmf3_broadcast_kind")
+        plan["kind"] = (kind, ni.value, nj.value)
+    return plan["kind"]
+
+
 class _VMF3RSample(torch.autograd.Function):
+    """z = rsample(loc, scale) for given or in-kernel noise.  With softplus=True `scale` is the RAW output of the
+    concentration head, the kernels use kappa = softplus(raw) + 1, and the function returns (z, kappa): both outputs
+    are differentiable and one backward launch serves both (no separate softplus / add passes in either direction)."""
+
     @staticmethod
-    def forward(ctx, loc, scale, u, eps, plan, seed, offset, offset_dev=None):
+    def forward(ctx, loc, scale, u, eps, plan, seed, offset, offset_dev=None, softplus=False):
         dev = _lib.require_hip(loc, scale, u, eps)
         locc, scalec = loc.detach().contiguous(), scale.detach().contiguous()
         uc = None if u is None else u.contiguous()
         epsc = None if eps is None else eps.contiguous()
         z = torch.empty(plan["o_shape"] + (3,), device=dev, dtype=loc.dtype)
+        kappa = torch.empty_like(scalec) if softplus else None
+        flags = _lib.FLAG_SOFTPLUS_KAPPA if softplus else 0
         if z.numel():
             with torch.cuda.device(dev):
                 rc = _lib.lib().vmf3_rsample_fwd(
-                    _lib.ptr(locc), _lib.ptr(scalec), _lib.ptr(uc), _lib.ptr(epsc), _lib.ptr(z), None,
+                    _lib.ptr(locc), _lib.ptr(scalec), _lib.ptr(uc), _lib.ptr(epsc), _lib.ptr(z), None, _lib.ptr(kappa),
                     len(plan["odims"]), _lib.i64_array(plan["odims"]), _lib.i64_array(plan["w_str"]),
                     _lib.i64_array(plan["k_str"]), _lib.i64_array(plan["l_str"]), _lib.i64_array(plan["e_str"]),
-                    _lib.dtype_code(loc), seed, offset, _lib.ptr(offset_dev), _lib.stream_ptr(dev))
+                    flags, _lib.dtype_code(loc), seed, offset, _lib.ptr(offset_dev), _lib.stream_ptr(dev))
             _lib.check(rc, "vmf3_rsample_fwd")
+        elif softplus and kappa.numel():
+            kappa = torch.nn.functional.softplus(scalec) + 1  # nothing to sample: no kernel ran
         ctx.save_for_backward(locc, scalec, uc, epsc)
-        ctx.plan, ctx.seed, ctx.offset, ctx.offset_dev = plan, seed, offset, offset_dev
+        ctx.plan, ctx.seed, ctx.offset, ctx.offset_dev, ctx.flags = plan, seed, offset, offset_dev, flags
         ctx.loc_shape, ctx.scale_shape = loc.shape, scale.shape
-        return z
+        return (z, kappa.view(scale.shape)) if softplus else z
 
     @staticmethod
-    def backward(ctx, gz):
+    def backward(ctx, gz, gkappa=None):
         locc, scalec, uc, epsc = ctx.saved_tensors
-        plan = ctx.plan
+        plan, flags = ctx.plan, ctx.flags
         dev = locc.device
+        lib = _lib.lib()
         gzc = gz.to(locc.dtype).contiguous()
+        gkc = None if gkappa is None else gkappa.to(locc.dtype).contiguous()
         odims, n_out = plan["odims"], _numel(plan["odims"])
         n_loc, n_scale = locc.numel() // 3, scalec.numel()
+        kind, n_i, n_j = _plan_kind(plan) if n_out else (_lib.KIND_GENERAL, 0, 0)
+        common = (flags, _lib.dtype_code(locc), ctx.seed, ctx.offset, _lib.ptr(ctx.offset_dev), _lib.stream_ptr(dev))
+        if kind == _lib.KIND_OUTER:
+            # the (B, 1)-scale broadcast: one pass over grad z, sums over i and over j inside the library (fixed order)
+            dloc, dscale = torch.empty_like(locc), torch.empty_like(scalec)
+            nbytes = _lib.C.c_int64(0)
+            _lib.check(lib.vmf3_rsample_bwd_outer_workspace(n_i, n_j, _lib.dtype_code(locc), _lib.C.byref(nbytes)),
+                       "vmf3_rsample_bwd_outer_workspace")
+            ws = torch.empty((nbytes.value + 7) // 8, device=dev, dtype=torch.float64)
+            with torch.cuda.device(dev):
+                rc = lib.vmf3_rsample_bwd_outer(_lib.ptr(locc), _lib.ptr(scalec), _lib.ptr(uc), _lib.ptr(epsc),
+                                                _lib.ptr(gzc), _lib.ptr(gkc), _lib.ptr(dloc), _lib.ptr(dscale), n_i, n_j,
+                                                _lib.ptr(ws), ws.numel() * 8, *common)
+            _lib.check(rc, "vmf3_rsample_bwd_outer")
+            return (dloc.reshape(ctx.loc_shape), dscale.reshape(ctx.scale_shape)) + (None,) * 7
         shared = not (n_loc == n_out and n_scale == n_out)
-        # Rows that share a loc row / scale element (the (B, 1) scale of the VAEs, sample shapes): by default the kernel
+        # Any other broadcast with rows that share a loc row / scale element (sample shapes ...): by default the kernel
         # writes one gradient row per output row and torch sums them (same bits every run); VMF_ATOMIC_BWD=1 lets the
         # kernel combine them with float atomics instead (no temporary, order varies run to run).
         per_row = shared and n_out > 0 and os.environ.get("VMF_ATOMIC_BWD", "0") != "1"
@@ -112,21 +151,46 @@ class _VMF3RSample(torch.autograd.Function):
             dscale = torch.empty(tuple(odims), device=dev, dtype=locc.dtype)
         else:
             dloc, dscale = torch.empty_like(locc), torch.empty_like(scalec)
+        in_kernel_gk = gkc is not None and not shared and kind == _lib.KIND_ROWS
         if dloc.numel() or dscale.numel():
             with torch.cuda.device(dev):
-                rc = _lib.lib().vmf3_rsample_bwd(
-                    _lib.ptr(locc), _lib.ptr(scalec), _lib.ptr(uc), _lib.ptr(epsc), _lib.ptr(gzc), _lib.ptr(dloc),
-                    _lib.ptr(dscale), n_out if per_row else n_loc, n_out if per_row else n_scale, len(odims),
+                rc = lib.vmf3_rsample_bwd(
+                    _lib.ptr(locc), _lib.ptr(scalec), _lib.ptr(uc), _lib.ptr(epsc), _lib.ptr(gzc),
+                    _lib.ptr(gkc) if in_kernel_gk else None, _lib.ptr(dloc), _lib.ptr(dscale),
+                    n_out if per_row else n_loc, n_out if per_row else n_scale, len(odims),
                     _lib.i64_array(odims), _lib.i64_array(plan["w_str"]), _lib.i64_array(plan["k_str"]),
-                    _lib.i64_array(plan["l_str"]), _lib.i64_array(plan["e_str"]), _lib.dtype_code(locc), ctx.seed,
-                    ctx.offset, _lib.ptr(ctx.offset_dev), _lib.stream_ptr(dev))
+                    _lib.i64_array(plan["l_str"]), _lib.i64_array(plan["e_str"]), *common)
             _lib.check(rc, "vmf3_rsample_bwd")
         if per_row:
             ldims = [d for d, (n, st) in enumerate(zip(odims, plan["l_str"])) if st == 0 and n > 1]
             kdims = [d for d, (n, st) in enumerate(zip(odims, plan["k_str"])) if st == 0 and n > 1]
             dloc = dloc.sum(dim=ldims) if ldims else dloc
             dscale = dscale.sum(dim=kdims) if kdims else dscale
-        return dloc.reshape(ctx.loc_shape), dscale.reshape(ctx.scale_shape), None, None, None, None, None, None
+        dscale = dscale.reshape(ctx.scale_shape)
+        if gkc is not None and not in_kernel_gk:  # rare shapes: the kappa output's own chain rule with torch ops
+            dscale = dscale + gkc.reshape(ctx.scale_shape) * torch.sigmoid(scalec.reshape(ctx.scale_shape))
+        return (dloc.reshape(ctx.loc_shape), dscale) + (None,) * 7
+
+
+def vmf3_rsample_from_heads(loc, scale_raw, sample_shape=torch.Size()):
+    """(z, kappa) straight from the two encoder heads: loc is the un-normalised output of the mean head (B, 3),
+    scale_raw the raw output of the concentration head; kappa = softplus(scale_raw) + 1 (model/spherical_vae.py:68-72,
+    model/torus_vae.py:101-105, CNN_experiment/circular_VAE.py:47-51) is evaluated inside the sampler kernel and
+    returned next to z = VonMisesFisher3D(loc, kappa).rsample(sample_shape).  Same noise as rsample() (u then eps from
+    torch's generator, or the in-kernel streams when VMF_RNG=philox); both outputs carry gradients to both heads."""
+    sample_shape = torch.Size(sample_shape)
+    assert loc.shape[-1] == 3, "This simple version o"
+    scale_raw = scale_raw if scale_raw.dtype == loc.dtype else scale_raw.to(loc.dtype)
+    _lib.require_hip(loc, scale_raw)
+    plan = vmf3_broadcast_plan(loc.shape, scale_raw.shape, sample_shape)
+    if rng.rng_mode() == "torch":
+        u = torch.rand(plan["w_shape"], device=loc.device, dtype=loc.dtype)          # :56
+        eps = torch.randn(plan["e_shape"] + (3,), device=loc.device, dtype=loc.dtype)  # :75
+        seed, offset, offset_dev = 0, 0, None
+    else:
+        u = eps = None
+        seed, offset, offset_dev = rng.default_generator.ticket(loc.device)
+    return _VMF3RSample.apply(loc, scale_raw, u, eps, plan, seed, offset, offset_dev, True)
 
 
 class _VMF3SampleW(torch.autograd.Function):

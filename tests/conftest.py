@@ -34,3 +34,15 @@ def oracle():
 
     vmf_oracle.lib()
     return vmf_oracle
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """GPU runs: how much of each fp32 allowance the parity tests used (tests/test_gpu_parity.py records it)"""
+    mod = sys.modules.get("test_gpu_parity") or sys.modules.get("tests.test_gpu_parity")
+    margins = getattr(mod, "MARGINS", None)
+    if margins:
+        import json
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_margins.json"), "w") as f:
+            json.dump(margins, f, indent=1, sort_keys=True)

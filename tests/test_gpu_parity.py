@@ -46,13 +46,31 @@ def close(a, b, tag, atol64=1e-9, atol32=1e-4, rtol32=1e-4):
         np.testing.assert_allclose(a, b, rtol=rtol32, atol=atol32)
 
 
-def close_vmf3(z, z_ref, tag, loc, scale, u, eps, ss=()):
-    """fp64: |dz| <= 1e-9.  fp32: 1e-4 relative to the unit row norm, plus what the rounding of w itself allows:
-    the reference forms w = 1 + L/kappa in fp32 with L = logsumexp(log u, log(1-u) - 2 kappa), so an error of a few
-    ulp in L (|L| <~ max(1, |log u|)) becomes dw = dL/kappa -- 1e-4 already at kappa = 1e-3 -- and z = w l + f v
-    moves by dw (1 + |w|/f).  Any fp32 evaluation of the reference's formula, the reference's own included, moves by
-    that much when log() differs in its last bit."""
+MARGINS = {}  # name -> {"max_err": ..., "used": largest error / allowance}; written to gpurun_out/ at the end of the run
+
+
+def record_margin(name, err, tol):
+    err, tol = np.asarray(err, dtype=np.float64), np.asarray(tol, dtype=np.float64)
+    used = float(np.nanmax(err / tol)) if err.size else 0.0
+    m = MARGINS.setdefault(name, {"max_err": 0.0, "used": 0.0})
+    m["max_err"] = max(m["max_err"], float(np.nanmax(err)) if err.size else 0.0)
+    m["used"] = max(m["used"], used)
+    return used
+
+
+def close_vmf3(z, z_ref, tag, loc, scale, u, eps, ss=(), name="vmf3"):
+    """fp64: |dz| <= 1e-9.  fp32: what the rounding of w itself allows, plus 2e-6 for the rest of the row: the reference
+    forms w = 1 + L/kappa in fp32 with L = logsumexp(log u, log(1-u) - 2 kappa), so an error of a few ulp in L
+    (|L| <~ max(1, |log u|)) becomes dw = dL/kappa -- 1e-4 already at kappa = 1e-3 -- and z = w l + f v moves by
+    dw (1 + |w|/f).  Any fp32 evaluation of the reference's formula, the reference's own included, moves by that much
+    when log() differs in its last bits.  dL is budgeted at 16 ulp of max(1, |log u|): the kernels chain five 1-ulp
+    hardware log2 / exp2 (each followed by a multiplication with ln 2 or its inverse) and the fp32 reference values
+    come from a chain of libm calls of their own.  The measured error and the share of the allowance it uses are
+    recorded (MARGINS); the contract's 1e-4 relative is asserted on top for every row whose w is not that
+    ill-conditioned."""
+    err = np.abs(z.astype(np.float64) - z_ref.astype(np.float64))
     if tag == "f64":
+        record_margin(name + "_f64", err, np.full_like(err, 1e-9))
         np.testing.assert_allclose(z, z_ref, rtol=0, atol=1e-9)
         return
     from oracle import vmf_oracle as orc
@@ -60,13 +78,23 @@ def close_vmf3(z, z_ref, tag, loc, scale, u, eps, ss=()):
     _, w64 = orc.vmf3_rsample_fwd(loc.astype(np.float64), k64, u64, eps.astype(np.float64), sample_shape=ss)
     f64 = np.sqrt(np.clip(1 - w64 * w64, 1e-10, 1.0))
     with np.errstate(divide="ignore"):
-        dL = 4 * 2.0 ** -24 * np.maximum(1.0, np.abs(np.log(np.maximum(u64, 1e-300))))
-    dw = 2.0 ** -24 + dL / np.broadcast_to(k64, w64.shape)
-    tol = 1e-4 + dw * (1 + np.abs(w64) / f64)
-    tol = np.broadcast_to(tol[..., None], z_ref.shape)
-    err = np.abs(z.astype(np.float64) - z_ref.astype(np.float64))
-    bad = err > tol + 1e-4 * np.abs(z_ref)
-    assert not bad.any(), (int(bad.sum()), float(err[bad].max()))
+        dL = 16 * 2.0 ** -24 * np.maximum(1.0, np.abs(np.log(np.maximum(u64, 1e-300))))
+    # one ulp for the final rounding of w, one for w^2 in 1 - w^2 (a fused multiply-add does not round it)
+    dw = 2.0 ** -23 + dL / np.broadcast_to(k64, w64.shape)
+    # the tangent t = eps - <eps, l> l cancels when eps is nearly parallel to loc: the few ulp of l and <eps, l> come
+    # back amplified by |eps| / |t| in v = t / |t| (8 ulp budgeted, scaled by the factor f that multiplies v)
+    l64 = loc.astype(np.float64)
+    l64 = l64 / (np.linalg.norm(l64, axis=-1, keepdims=True) + 1e-5)
+    e64 = np.broadcast_to(eps.astype(np.float64), tuple(ss) + loc.shape)
+    t64 = e64 - (e64 * l64).sum(-1, keepdims=True) * l64
+    cond = np.linalg.norm(e64, axis=-1) / np.maximum(np.linalg.norm(t64, axis=-1), 1e-30)
+    tol = (2e-6 + dw * (1 + np.abs(w64) / f64))[..., None] + f64[..., None] * (8 * 2.0 ** -24 * cond)[..., None]
+    tol = np.broadcast_to(tol, z_ref.shape)
+    used = record_margin(name + "_f32", err, tol)
+    bad = err > tol
+    assert not bad.any(), (int(bad.sum()), float(err[bad].max()), used)
+    well = tol < 2e-5
+    assert (err[well] <= 1e-4).all()  # the contract: 1e-4 relative to the (unit) row norm; in fact < 2e-5 by `well`
 
 
 def test_library_loaded_is_in_tree():
@@ -139,6 +167,105 @@ def test_vmf3_backward_fp32_vs_oracle(oracle, outer):
     np.testing.assert_allclose(N(tk.grad), dk_ref, rtol=2e-3, atol=2e-3 * sc_k)
 
 
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("shape", ["rows", "outer", "sample_shape"])
+def test_vmf3_softplus_fold_matches_torch_softplus(monkeypatch, tag, shape):
+    """kappa = softplus(raw) + 1 evaluated inside the sampler kernels (model/spherical_vae.py:68-72) against torch's
+    softplus in front of the plain path: z, the returned kappa, and the gradients of a loss that uses both"""
+    from medicalimageanalysis_amd.sampler.von_mises_fisher import vmf3_rsample_from_heads
+    monkeypatch.setenv("VMF_RNG", "torch")
+    dt = TD[tag]
+    g = torch.Generator(device=DEV).manual_seed(21)
+    if shape == "rows":
+        nl, ks, ss = 1000, (1000,), ()
+    elif shape == "outer":
+        nl, ks, ss = 300, (260, 1), ()
+    else:
+        nl, ks, ss = 40, (40,), (3,)
+    loc = torch.randn(nl, 3, device=DEV, generator=g, dtype=dt)
+    raw = torch.rand(ks, device=DEV, generator=g, dtype=dt) * 32 - 6     # crosses softplus' threshold at 20
+    la, ra = loc.clone().requires_grad_(), raw.clone().requires_grad_()
+    lb, rb = loc.clone().requires_grad_(), raw.clone().requires_grad_()
+    torch.manual_seed(5)
+    z, kap = vmf3_rsample_from_heads(la, ra, ss)
+    torch.manual_seed(5)
+    kap_ref = torch.nn.functional.softplus(rb) + 1
+    q = VonMisesFisher3D(lb, kap_ref, validate_args=False)
+    u = torch.rand(torch.Size(ss) + raw.shape, device=DEV, dtype=dt)
+    eps = torch.randn(torch.Size(ss) + loc.shape, device=DEV, dtype=dt)
+    z_ref = q.rsample_with_noise(u, eps, ss)
+    assert z.shape == z_ref.shape and kap.shape == raw.shape
+    c = torch.randn(z.shape, device=DEV, generator=g, dtype=dt)
+    d = torch.randn(raw.shape, device=DEV, generator=g, dtype=dt)
+    ((z * c).sum() + (kap * d).sum()).backward()
+    ((z_ref * c).sum() + (kap_ref * d).sum()).backward()
+    if tag == "f64":
+        np.testing.assert_allclose(N(kap), N(kap_ref), rtol=1e-14)
+        np.testing.assert_allclose(N(z), N(z_ref), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(N(la.grad), N(lb.grad), rtol=1e-9, atol=1e-9 * float(lb.grad.abs().max()))
+        np.testing.assert_allclose(N(ra.grad), N(rb.grad), rtol=1e-9, atol=1e-9 * float(rb.grad.abs().max()))
+    else:
+        np.testing.assert_allclose(N(kap), N(kap_ref), rtol=2e-6)
+        np.testing.assert_allclose(N(z), N(z_ref), rtol=0, atol=2e-5)   # kappa moves by an ulp, w by |L| / kappa of it
+        np.testing.assert_allclose(N(la.grad), N(lb.grad), rtol=2e-3, atol=2e-3 * float(lb.grad.abs().max()))
+        np.testing.assert_allclose(N(ra.grad), N(rb.grad), rtol=2e-3, atol=2e-3 * float(rb.grad.abs().max()))
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("ni,nj", [(260, 516), (7, 5), (1000, 64), (65, 257)])
+def test_vmf3_outer_product_shapes_vs_oracle(oracle, tag, ni, nj):
+    """(n_i, 1) scale against (n_j, 3) loc: full and partial column tiles, odd widths (scalar accesses), more rows than
+    one block takes; forward and the in-library reduction of the backward against the oracle's per-row sums"""
+    gen = np.random.default_rng(100 + ni)
+    dt = np.float64 if tag == "f64" else np.float32
+    loc = gen.standard_normal((nj, 3)).astype(dt)
+    scale = np.exp(gen.uniform(0, np.log(1e3), (ni, 1))).astype(dt)
+    u = gen.uniform(0.01, 0.99, size=(ni, 1)).astype(dt)
+    eps = gen.standard_normal((nj, 3)).astype(dt)
+    c = gen.standard_normal((ni, nj, 3)).astype(dt)
+    z_ref, _ = oracle.vmf3_rsample_fwd(loc, scale, u, eps)
+    dl_ref, dk_ref = oracle.vmf3_rsample_bwd(loc.astype(np.float64), scale.astype(np.float64), u.astype(np.float64),
+                                             eps.astype(np.float64), c.astype(np.float64))
+    tl, tk = T(loc).requires_grad_(), T(scale).requires_grad_()
+    z = VonMisesFisher3D(tl, tk, validate_args=False).rsample_with_noise(T(u), T(eps))
+    assert z.shape == (ni, nj, 3)
+    close_vmf3(N(z), z_ref, tag, loc, scale, u, eps, name="vmf3_outer")
+    (z * T(c)).sum().backward()
+    rt = 1e-9 if tag == "f64" else 2e-3
+    np.testing.assert_allclose(N(tl.grad), dl_ref, rtol=rt, atol=rt * np.abs(dl_ref).max())
+    np.testing.assert_allclose(N(tk.grad), dk_ref, rtol=rt, atol=rt * np.abs(dk_ref).max())
+    # same bits on a second run (fixed summation order, no atomics)
+    g1, g2 = tl.grad.clone(), tk.grad.clone()
+    tl.grad = tk.grad = None
+    (VonMisesFisher3D(tl, tk, validate_args=False).rsample_with_noise(T(u), T(eps)) * T(c)).sum().backward()
+    assert torch.equal(g1, tl.grad) and torch.equal(g2, tk.grad)
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_vmf3_unaligned_views_take_the_scalar_path(oracle, tag):
+    """operands that start one row into an allocation are not 16-byte aligned: same results through scalar accesses"""
+    gen = np.random.default_rng(31)
+    dt = np.float64 if tag == "f64" else np.float32
+    B = 777
+    loc = gen.standard_normal((B + 1, 3)).astype(dt)
+    scale = np.exp(gen.uniform(0, np.log(1e3), B + 1)).astype(dt)
+    u = gen.uniform(0.01, 0.99, size=B + 1).astype(dt)
+    eps = gen.standard_normal((B + 1, 3)).astype(dt)
+    c = gen.standard_normal((B + 1, 3)).astype(dt)
+    tl, tk = T(loc)[1:].requires_grad_(), T(scale)[1:].requires_grad_()
+    assert tl.data_ptr() % 16 != 0 and tl.is_contiguous()
+    z = VonMisesFisher3D(tl, tk, validate_args=False).rsample_with_noise(T(u)[1:], T(eps)[1:])
+    z_ref, _ = oracle.vmf3_rsample_fwd(loc[1:], scale[1:], u[1:], eps[1:])
+    close_vmf3(N(z), z_ref, tag, loc[1:], scale[1:], u[1:], eps[1:], name="vmf3_unaligned")
+    (z * T(c)[1:]).sum().backward()
+    dl_ref, dk_ref = oracle.vmf3_rsample_bwd(loc[1:].astype(np.float64), scale[1:].astype(np.float64),
+                                             u[1:].astype(np.float64), eps[1:].astype(np.float64),
+                                             c[1:].astype(np.float64))
+    rt = 1e-9 if tag == "f64" else 2e-3
+    np.testing.assert_allclose(N(tl.grad), dl_ref, rtol=rt, atol=rt * np.abs(dl_ref).max())
+    np.testing.assert_allclose(N(tk.grad), dk_ref, rtol=rt, atol=rt * np.abs(dk_ref).max())
+
+
 def test_vmf3_torch_rng_mode_replays_reference_draw_order(monkeypatch):
     """VMF_RNG=torch: u then eps from torch's generator, as sampler/von_mises_fisher.py:56,75"""
     monkeypatch.setenv("VMF_RNG", "torch")
@@ -154,30 +281,41 @@ def test_vmf3_torch_rng_mode_replays_reference_draw_order(monkeypatch):
     assert torch.equal(z, q.rsample_with_noise(u, eps))
 
 
-def test_vmf3_philox_mode_vs_oracle(monkeypatch, oracle):
+@pytest.mark.parametrize("shape", ["rows_small", "rows_tiles", "outer"])
+def test_vmf3_philox_mode_vs_oracle(monkeypatch, oracle, shape):
+    """in-kernel noise: u_i from Philox(index i, slot 0), eps row j from Philox(index j, slot 1), whichever kernel the
+    shape takes (scalar rows, staged 256-row tiles, the outer product) -- forward and the backward's regenerated noise"""
     monkeypatch.setenv("VMF_RNG", "philox")
     lib = oracle.lib()
     gen = np.random.default_rng(9)
-    B = 200
-    loc = gen.standard_normal((B, 3))
-    scale = np.exp(gen.uniform(0, np.log(1e3), B))
+    ni, nj = {"rows_small": (200, 200), "rows_tiles": (700, 700), "outer": (70, 300)}[shape]
+    loc = gen.standard_normal((nj, 3))
+    scale = np.exp(gen.uniform(0, np.log(1e3), (ni, 1) if shape == "outer" else ni))
     g0 = rng.PhiloxGenerator(seed=0xABCDEF0123, offset=5)
     monkeypatch.setattr(rng, "default_generator", g0)
-    z = VonMisesFisher3D(T(loc), T(scale), validate_args=False).rsample()
-    # rebuild the noise with the oracle's Philox: u from (index i, slot 0).x, eps row from (index i, slot 1)
+    tl, tk = T(loc).requires_grad_(), T(scale).requires_grad_()
+    z = VonMisesFisher3D(tl, tk, validate_args=False).rsample()
+    # rebuild the noise with the oracle's Philox
     out = (C.c_uint32 * 4)()
-    u = np.empty(B)
-    eps = np.empty((B, 3))
-    for i in range(B):
+    u = np.empty(ni)
+    eps = np.empty((nj, 3))
+    for i in range(ni):
         lib.orc_philox4x32_10(C.c_uint64(i), C.c_uint32(0), C.c_uint64(0xABCDEF0123), C.c_uint64(5), out)
         u[i] = lib.orc_u01(out[0])
+    for i in range(nj):
         lib.orc_philox4x32_10(C.c_uint64(i), C.c_uint32(1), C.c_uint64(0xABCDEF0123), C.c_uint64(5), out)
         uu = [lib.orc_u01(out[j]) for j in range(4)]
         r0, r1 = np.sqrt(-2 * np.log(uu[0])), np.sqrt(-2 * np.log(uu[2]))
         eps[i] = [r0 * np.cos(2 * np.pi * uu[1]), r0 * np.sin(2 * np.pi * uu[1]), r1 * np.cos(2 * np.pi * uu[3])]
+    u = u.reshape(scale.shape)
     z_ref, _ = oracle.vmf3_rsample_fwd(loc, scale, u, eps)
     np.testing.assert_allclose(N(z), z_ref, rtol=0, atol=1e-9)
     assert g0.get_state()["offset"] == 6
+    c = gen.standard_normal(z_ref.shape)
+    (z * T(c)).sum().backward()
+    dl_ref, dk_ref = oracle.vmf3_rsample_bwd(loc, scale, u, eps, c)
+    np.testing.assert_allclose(N(tl.grad), dl_ref, rtol=1e-8, atol=1e-9 * np.abs(dl_ref).max())
+    np.testing.assert_allclose(N(tk.grad), dk_ref, rtol=1e-8, atol=1e-9 * np.abs(dk_ref).max())
 
 
 @pytest.mark.parametrize("tag", ["f64", "f32"])
@@ -381,8 +519,9 @@ def test_sample_w3_matches_reference(golden, tag, monkeypatch):
 
 
 def test_vmf3_broadcast_backward_is_reproducible_and_matches_atomics(monkeypatch):
-    """(B, 1) scale -> (B, B, 3): per-row gradients summed by torch give the same bits on every run; the atomic
-    variant agrees to rounding; a sample shape with an elementwise scale reduces over the right dimension"""
+    """(B, 1) scale -> (B, B, 3): the in-library reduction gives the same bits on every run (VMF_ATOMIC_BWD only
+    concerns other broadcasts); a sample shape with an elementwise scale -- per-row gradients summed by torch, or
+    float atomics -- reduces over the right dimension"""
     gen = torch.Generator(device=DEV).manual_seed(12)
     B = 96
     loc = torch.randn(B, 3, device=DEV, generator=gen).requires_grad_()

@@ -63,6 +63,44 @@ def test_broadcast_plan_matches_numpy_broadcasting(oracle, loc, scale, ss):
         assert np.array_equal(a, b), key
 
 
+@pytest.mark.parametrize("loc,scale,ss,kind,ni,nj", [
+    ((33, 3), (33,), (), 1, 33, 33),          # CircularVAE: kappa squeezed to (B,)
+    ((33, 3), (33, 1), (), 2, 33, 33),        # SphericalVAE / ToroidalVAE: (B, 1) kappa -> (B, B, 3)
+    ((2, 3, 3), (2, 3), (), 1, 6, 6),         # batch dims collapse to rows
+    ((5, 3), (7, 1), (), 2, 7, 5),            # outer product with different sizes
+    ((19, 3), (19,), (5,), 0, 0, 0),          # sample shape in front of shared parameters
+    ((4, 3), (4, 1), (4,), 0, 0, 0),
+    ((3,), (), (), 1, 1, 1),
+    ((1, 3), (6, 1), (), 0, 0, 0),            # one loc row against six scales: eps has one row too, no outer product
+])
+def test_broadcast_kind_classification(loc, scale, ss, kind, ni, nj):
+    """which kernel a call takes is decided on the host from the broadcast description alone"""
+    from medicalimageanalysis_amd import _lib
+    from medicalimageanalysis_amd.sampler.von_mises_fisher import _plan_kind, vmf3_broadcast_plan
+
+    got = _plan_kind(vmf3_broadcast_plan(loc, scale, ss))
+    assert got[0] == kind
+    if kind:
+        assert got[1:] == (ni, nj)
+    assert (_lib.KIND_GENERAL, _lib.KIND_ROWS, _lib.KIND_OUTER) == (0, 1, 2)
+
+
+def test_outer_backward_workspace_size_is_reported_without_a_gpu():
+    from medicalimageanalysis_amd import _lib
+
+    lib = _lib.lib()
+    nb = C.c_int64(-1)
+    assert lib.vmf3_rsample_bwd_outer_workspace(4096, 4096, _lib.VMF_F32, C.byref(nb)) == 0
+    # one (a, b) pair per row and 256-column tile, one (dl, dv) pair per column and 64-row tile: 3.4 % of grad z
+    assert nb.value == (16 * 4096 * 2 + 64 * 4096 * 6) * 4
+    assert lib.vmf3_rsample_bwd_outer_workspace(128, 128, _lib.VMF_F64, C.byref(nb)) == 0 and nb.value > 0
+    assert lib.vmf3_rsample_bwd_outer_workspace(-1, 4, _lib.VMF_F32, C.byref(nb)) == -1
+    # too small a workspace is refused before anything is launched
+    rc = lib.vmf3_rsample_bwd_outer(C.c_void_p(16), C.c_void_p(16), None, None, C.c_void_p(16), None, C.c_void_p(16),
+                                    C.c_void_p(16), 64, 64, C.c_void_p(16), 8, 0, 0, 0, 0, None, None)
+    assert rc == -1 and b"workspace" in lib.vmf_last_error_string()
+
+
 def test_broadcast_plan_rejects_incompatible_shapes():
     from medicalimageanalysis_amd.sampler.von_mises_fisher import vmf3_broadcast_plan
 
