@@ -336,6 +336,48 @@ def test_two_rank_sharded_sampling_on_the_device(tmp_path):
         assert p.returncode == 0 and f"rank {r} ok" in o, o
 
 
+def test_bench_launches_two_ranks_itself_on_the_shared_device():
+    """`python bench.py --gpus 2` with no launcher: the parent starts both ranks before touching the GPU; on a one-GPU
+    box they share the device (gloo rendezvous).  Both ranks' kernel times come back and the rate counts both."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rows",
+                          str(1 << 20), "--cpu-rows", "0", "--steps", "5", "--warmup", "2", "--with-allreduce"], cwd=root,
+                         env=env, capture_output=True, text=True, timeout=110)
+    assert run.returncode == 0, run.stdout + run.stderr
+    lines = [l for l in run.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, run.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and "rehearsal" not in rec
+    assert len(rec["kernel_ms_per_rank"]) == 2 and all(t and t > 0 for t in rec["kernel_ms_per_rank"])
+    assert abs(rec["value"] - 2 * (1 << 20) * 5 / (rec["ms_per_step"] * 5e-3)) < 1e-6 * rec["value"]
+    assert rec["allreduce"]["count_seen"] == 2 * (1 << 20) and rec["roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("config", [1, 2, 4, 5])
+def test_bench_other_configurations_produce_a_record(config):
+    """every BASELINE configuration comes out of bench.py as one JSON line with roofline and cpu_baseline (sizes cut
+    down here; the driver-sized runs are in profiles/)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows = {1: 4096, 2: 128, 4: 1 << 14, 5: 1 << 12}[config]
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", str(config), "--rows", str(rows),
+                          "--cpu-rows", "2048", "--steps", "3", "--warmup", "2"], cwd=root, capture_output=True, text=True,
+                         timeout=110)
+    assert run.returncode == 0, run.stdout + run.stderr
+    rec = json.loads(run.stdout.strip().splitlines()[-1])
+    assert rec["config"]["bench_config"] == config and rec["value"] > 0 and rec["n_gpus"] == 1
+    assert rec["roofline"]["bound"] == "hbm" and rec["roofline"]["achieved"] > 0
+    assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["cores"] >= 1
+
+
 def test_c_abi_driver_without_python_runs_the_headline_kernel():
     """medicalimageanalysis_amd/abi_bench (tools/abi_bench.hip) links only libvmf_hip.so and the HIP runtime: the
     same entry points from plain C++ with hipMalloc'ed buffers"""

@@ -302,3 +302,32 @@ def test_two_rank_gloo_sharding_and_scalar_allreduce(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o
+
+
+def _run_bench(*flags, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=timeout)
+    return out
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no torchrun around it: the parent starts two rank processes, they meet over gloo,
+    time between barriers, reduce the maximum, and rank 0's single JSON line comes back with n_gpus 2.  --rehearse
+    leaves the GPU out (this machine has none); the GPU suite runs the same launcher with real kernels."""
+    import json
+    out = _run_bench("--gpus", "2", "--backend", "gloo", "--rows", "4096", "--cpu-rows", "0", "--steps", "3", "--warmup",
+                     "1", "--with-allreduce", "--rehearse")
+    assert out.returncode == 0, out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["rehearsal"] is True and rec["steps"] == 3
+    assert len(rec["kernel_ms_per_rank"]) == 2
+    assert rec["allreduce"]["count_seen"] == 2 * 4096      # the packed scalars really went through the collective
+
+
+def test_bench_fails_when_a_rank_fails():
+    out = _run_bench("--gpus", "2", "--rows", "4096", "--cpu-rows", "0", "--steps", "1", "--warmup", "0", "--backend",
+                     "no-such-backend")
+    assert out.returncode != 0

@@ -221,3 +221,48 @@ def test_s1_projected_normal(golden, oracle, tag):
     np.testing.assert_allclose(z, g[f"pn_z_{tag}"], **tol)
     z = oracle.s1_projnormal_fwd(g["mean_vec"], g["kappa"], g["noise"])
     np.testing.assert_allclose(z, g["z"], rtol=0, atol=1e-13)
+
+
+# ---- the torch-op restatement that bench.py times as the CPU baseline of the m = 3 configurations ---------------------
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("case,ss", [("ew_{}_s0_", ()), ("outer_{}_s1_", ()), ("ss5_{}_", (5,)), ("nd_{}_", ())])
+def test_reference_torch_rsample(golden, tag, case, ss):
+    import torch
+    from oracle import reference_torch as rt
+
+    g = golden("g_rsample")
+    p = case.format(tag)
+    t = lambda k: torch.from_numpy(g[p + k])  # noqa: E731
+    z, _ = rt.rsample(t("loc"), t("scale"), ss, noise=(t("u"), t("eps")))
+    assert tuple(z.shape) == g[p + "z"].shape
+    if tag == "f64":
+        np.testing.assert_allclose(z.numpy(), g[p + "z"], rtol=0, atol=F64_ATOL)
+    else:
+        _close32(z.numpy(), g[p + "z"])
+
+
+def test_reference_torch_kl_and_vae_step(golden):
+    import torch
+    from oracle import reference_torch as rt
+
+    g = golden("g_kl")
+    for tag in ("f64", "f32"):
+        k = g[f"kappa_{tag}"]
+        got = rt.kl_spherical(torch.from_numpy(k)).numpy()
+        ok = ~sinh_window(k)
+        # fp32: log k - log sinh k cancels below kappa ~ 0.1, libm-to-libm differences are absolute there
+        np.testing.assert_allclose(got[ok], g[f"spherical_{tag}"][ok], rtol=1e-12 if tag == "f64" else 1e-4,
+                                   atol=1e-12 if tag == "f64" else 2e-4, equal_nan=True)
+    g = golden("g_svae")
+    cfg = {k[5:]: g[k].item() for k in g.files if k.startswith("cfg::")}
+    cfg["device"] = "cpu"
+    model = rt.SphericalVAERef(cfg).double()
+    model.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w::")}, strict=False)
+    x = torch.from_numpy(g["x"])
+    z, x_mu, params = model(x, noise=(torch.from_numpy(g["u"]), torch.from_numpy(g["eps"])))
+    np.testing.assert_allclose(z.detach().numpy(), g["z"], rtol=0, atol=1e-12)
+    loss = model.elbo(x, x_mu, params)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-12)
+    loss.backward()
+    np.testing.assert_allclose(model.function_z_logvar.weight.grad.numpy(), g["g::function_z_logvar.weight"], rtol=1e-8,
+                               atol=1e-12)
