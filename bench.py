@@ -173,7 +173,7 @@ class GeneralRSample:
         if ev:
             ev[0].record()
         rc = self.lib.vmf_rsample_fwd(_lib.ptr(self.mu), self.m, _lib.ptr(self.kappa), 1, _lib.ptr(self.z), None, None, None,
-                                      _lib.ptr(self.logp), self.n, self.m, None, None, 0, None, 64, self.row0, self.seed, i,
+                                      _lib.ptr(self.logp), None, self.n, self.m, None, None, 0, None, 64, self.row0, self.seed, i,
                                       None, 0, _lib.VMF_F32, self.sp)
         if ev:
             ev[1].record()
@@ -343,7 +343,7 @@ class VAETrainStep:
         for i in range(30):
             if i >= 10:
                 ev[i - 10][0].record()
-            _lib.lib().vmf_rsample_fwd(_lib.ptr(mu), 10, _lib.ptr(kap), 1, _lib.ptr(z), None, None, None, None, self.B, 10,
+            _lib.lib().vmf_rsample_fwd(_lib.ptr(mu), 10, _lib.ptr(kap), 1, _lib.ptr(z), None, None, None, None, None, self.B, 10,
                                        None, None, 0, None, 64, 0, 1, i, None, 0, _lib.VMF_F32, sp)
             if i >= 10:
                 ev[i - 10][1].record()
@@ -421,7 +421,7 @@ class TorusAndS1:
         if ev:
             ev[0].record()
         rc = self.lib.vmf_rsample_fwd(_lib.ptr(self.mu), 2, _lib.ptr(self.kappa), 1, _lib.ptr(self.z), None, None, None, None,
-                                      n, 2, None, None, 0, None, 64, self.row0, self.seed, 2 * i, None, 0, _lib.VMF_F32,
+                                      None, n, 2, None, None, 0, None, 64, self.row0, self.seed, 2 * i, None, 0, _lib.VMF_F32,
                                       self.sp)
         if ev:
             ev[1].record()

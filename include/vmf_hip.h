@@ -194,18 +194,20 @@ int vmf_kl_bwd(const void* kappa, const void* gout, int64_t gout_stride, double 
  * proposals and gauss is (n, m) normals (column 0 ignored); all three must then be given.
  * The accepted proposal index (first accepted, or the last one tried when none is) goes to accept_idx.
  * Outputs w_out (n), omw_out (n; 1 - w computed without cancellation, what the backward wants),
- * accept_idx (n, int32), logp_out (n; log p(z) fused) are nullable. */
+ * accept_idx (n, int32), logp_out (n; log p(z) fused), kappa_out (n; the kappa the kernel used, of interest with
+ * VMF_FLAG_SOFTPLUS_KAPPA: the KL term needs it; kappa_stride must be 1 then) are nullable. */
 /* flags: VMF_FLAG_NORMALIZE_MU, VMF_FLAG_SOFTPLUS_KAPPA (defined with vmf3_rsample_fwd above) */
 int vmf_rsample_fwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, void* z, void* w_out,
-                    void* omw_out, int32_t* accept_idx, void* logp_out, int64_t n, int m, const void* prop_e, const void* prop_u,
+                    void* omw_out, int32_t* accept_idx, void* logp_out, void* kappa_out, int64_t n, int m, const void* prop_e, const void* prop_u,
                     int n_prop, const void* gauss, int max_prop, uint64_t row0, uint64_t seed, uint64_t offset,
                     const uint64_t* offset_dev, int flags, int dtype, vmf_stream_t stream);
 /* Backward through z given the saved w and 1-w (omw; null: 1-w is recomputed from w) -- path-wise through
  * b(kappa), the accepted proposal held fixed.
  * gauss null: the Gaussians are regenerated from the same counters.  dmu is (n, m); with mu_stride == 0 or
- * kappa_stride == 0 the caller reduces dmu / dkappa over rows. */
+ * kappa_stride == 0 the caller reduces dmu / dkappa over rows.  grad_kappa (n, nullable): gradient with respect to the
+ * forward call's kappa_out, added to dkappa before the softplus chain rule of VMF_FLAG_SOFTPLUS_KAPPA. */
 int vmf_rsample_bwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, const void* w,
-                    const void* omw, const void* grad_z, const void* gauss, void* dmu, void* dkappa, int64_t n, int m, uint64_t row0,
+                    const void* omw, const void* grad_z, const void* gauss, const void* grad_kappa, void* dmu, void* dkappa, int64_t n, int m, uint64_t row0,
                     uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int flags, int dtype,
                     vmf_stream_t stream);
 /* logp = k<mu,x> + log C_m(k),  log C_m = (m/2-1) log k - (m/2) log 2pi - (log ive(m/2-1,k) + k) */

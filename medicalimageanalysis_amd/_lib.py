@@ -47,9 +47,9 @@ _PROTOS = {
     "vmf_kl_fwd": [_P, _P, _P, _P, _D, _I64, _I, _I, _P],
     "vmf_kl_fwd_static": [_P, _P, _P, _D, _I64, _I, _I, _P],
     "vmf_kl_bwd": [_P, _P, _I64, _D, _P, _I64, _I, _I, _P],
-    "vmf_rsample_fwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _I, _P, _I, _U64, _U64, _U64, _P,
+    "vmf_rsample_fwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _I, _P, _I, _U64, _U64, _U64, _P,
                         _I, _I, _P],
-    "vmf_rsample_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I, _U64, _U64, _U64, _P, _I, _I, _P],
+    "vmf_rsample_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I, _U64, _U64, _U64, _P, _I, _I, _P],
     "vmf_log_prob_fwd": [_P, _I64, _P, _I64, _P, _P, _I64, _I, _I, _P],
     "vmf_log_prob_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _I, _I, _P],
     "vmf_entropy_kl_fwd": [_P, _P, _P, _P, _I64, _I, _I, _P],

@@ -91,10 +91,21 @@ struct GenParams {
   const T* prop_e; const T* prop_u; const T* gauss;
   int64_t n; int m; int max_prop; uint64_t row0;
   int normalize;  // mu rows are raw: use mu / ||mu|| (and chain the gradient through the normalisation)
+  int softplus;   // kappa holds raw head outputs: kappa = softplus(raw) + 1, gradient returned for the raw values
+  const T* gkappa;  // backward: gradient with respect to the forward's kappa output (nullable)
   PhiloxArg ka; VmfDim dim;
   // backward only
   const T* w_in; const T* omw_in; const T* gz; T* dmu; T* dkappa;
 };
+
+// kappa of a row: the stored value, or softplus(raw) + 1 when the call passes raw head outputs (VMF_FLAG_SOFTPLUS_KAPPA)
+template <typename T>
+__device__ __forceinline__ T kappa_of(T stored, bool softplus, T* sig) {
+  *sig = (T)1;
+  if (!softplus) return stored;
+  if (sizeof(T) == 4) return (T)v3_softplus_kappa<float, MFast>((float)stored, (float*)sig);
+  return (T)v3_softplus_kappa<double, M<double>>((double)stored, (double*)sig);
+}
 
 // load the 4 elements [e0, e0+4) of a row (zero beyond m)
 template <typename T, bool VEC, bool STREAM = false>
@@ -157,11 +168,12 @@ __device__ __forceinline__ void noise4(const T* __restrict__ grow_ptr, uint64_t 
 template <typename T>
 struct FwdParams {
   const T* mu; const T* kappa; T* z;
-  T* w_out; T* omw_out; int32_t* accept_idx; T* logp;
+  T* w_out; T* omw_out; int32_t* accept_idx; T* logp; T* kappa_out;
   const T* prop_e; const T* prop_u; const T* gauss;
   int64_t n; uint64_t row0;
   int mu_stride, kappa_stride, m, max_prop;
   int normalize;  // mu rows are raw: the sample is drawn around mu / ||mu||
+  int softplus;   // kappa holds raw head outputs: the tile prologue turns them into kappa = softplus(raw) + 1
   PhiloxArg ka;
   float lc_v, lc_lg, lc_c0;  // fp32 fused log_prob: m/2 - 1, lgamma(m/2), (m/2) log 2 pi
 };
@@ -237,9 +249,14 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
     // fp32 fused log_prob: log C_m(kappa) of the tile's rows, evaluated in single precision here (two rows per lane)
     // so that phase 2 writes log p once; fp64 outputs get theirs from the double-precision pre-pass kernel instead
     const bool lp32 = LP_SLAB && p.logp != nullptr;
-    if (lp32 || !pre) {
+    // (the exact-fit streaming instantiation is kept free of the softplus / kappa_out options, like `normalize`)
+    const bool sp = !FAST && p.softplus;
+    T* const kout = FAST ? nullptr : p.kappa_out;
+    if (lp32 || !pre || kout) {
       for (int i = lane; i < ntile; i += 64) {
-        const T kap = kap_t[i * p.kappa_stride];
+        T sig_;
+        const T kap = kappa_of<T>(kap_t[i * p.kappa_stride], sp, &sig_);
+        if (kout) kout[tile0 + i] = kap;
         if (lp32) {
           skp[i] = (float)kap;
           slc[i] = vmf_log_norm_f32v(p.lc_v, p.lc_lg, p.lc_c0, (float)kap);
@@ -255,7 +272,8 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
       T a = 0, b = 0, d = 0;
       bool neg = false;           // circle: the row's sign bit
       if (active) {
-        if (pre) wood_consts<T>(kap_t[my * p.kappa_stride], m, &a, &b, &d);
+        T sig_;
+        if (pre) wood_consts<T>(kappa_of<T>(kap_t[my * p.kappa_stride], sp, &sig_), m, &a, &b, &d);
         else b = somw[my];
       }
       while (__ballot(active) != 0ull) {
@@ -304,7 +322,8 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
           k = 0;
           active = my < ntile;
           if (active) {
-            if (pre) wood_consts<T>(kap_t[my * p.kappa_stride], m, &a, &b, &d);
+            T sig_;
+            if (pre) wood_consts<T>(kappa_of<T>(kap_t[my * p.kappa_stride], sp, &sig_), m, &a, &b, &d);
             else b = somw[my];
           }
         }
@@ -471,11 +490,13 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
           if (LP_SLAB) {
             slc[rr] += skp[rr] * (float)mz;  // written out coalesced once the tile is done
           } else if (sizeof(T) == 4) {       // circle: consecutive lanes hold consecutive rows
-            const float kap = (float)kap_t[rr * p.kappa_stride];
+            T sig_;
+            const float kap = (float)kappa_of<T>(kap_t[rr * p.kappa_stride], sp, &sig_);
             const float lc = CIRCLE ? vmf_log_norm_circle_f32(kap) : vmf_log_norm_f32v(p.lc_v, p.lc_lg, p.lc_c0, kap);
             p.logp[tile0 + rr] = (T)(lc + kap * (float)mz);
           } else {
-            p.logp[tile0 + rr] += kap_t[rr * p.kappa_stride] * mz;  // log C_m(kappa) came from the pre-pass
+            T sig_;
+            p.logp[tile0 + rr] += kappa_of<T>(kap_t[rr * p.kappa_stride], sp, &sig_) * mz;  // log C_m(kappa) came from the pre-pass
           }
         }
       }
@@ -540,7 +561,8 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
     dd = ((T)1 - mu0) * ((T)1 - mu0) + dd * (inv * inv);
     const T w = p.w_in[row];
     const T omw = p.omw_in ? p.omw_in[row] : (T)1 - w;
-    const T kap = p.kappa[row * p.kappa_stride];
+    T ksig;
+    const T kap = kappa_of<T>(p.kappa[row * p.kappa_stride], p.softplus != 0, &ksig);
     T c2 = omw * ((T)1 + w);
     const bool inside = c2 >= (T)1e-10;
     c2 = inside ? c2 : (T)1e-10;
@@ -601,7 +623,9 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
         const T e = omw * F<T>::rcp(((T)1 + b) - w * ((T)1 - b));
         const T den = (T)1 - ((T)1 - b) * e;
         const T dw_db = (T)-2 * e * ((T)1 - e) * F<T>::rcp(den * den);
-        p.dkappa[row] = dw * dw_db * ((T)-2 * b * F<T>::rcp(c));
+        T dk = dw * dw_db * ((T)-2 * b * F<T>::rcp(c));
+        if (p.gkappa) dk += p.gkappa[row];
+        p.dkappa[row] = dk * ksig;
       }
     }
   }
@@ -611,11 +635,13 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
 // out of the streaming kernel)
 template <typename T>
 __global__ __launch_bounds__(256) void vmf_log_norm_kernel(const T* __restrict__ kappa, int64_t kappa_stride,
-                                                           T* __restrict__ out, int64_t n, VmfDim dim) {
+                                                           T* __restrict__ out, int64_t n, VmfDim dim, int softplus) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    if (sizeof(T) == 4) out[i] = (T)vmf_log_norm_f32(dim, (float)kappa[i * kappa_stride]);
-    else out[i] = (T)vmf_log_norm(dim, (double)kappa[i * kappa_stride]);
+    T sig_;
+    const T kap = kappa_of<T>(kappa[i * kappa_stride], softplus != 0, &sig_);
+    if (sizeof(T) == 4) out[i] = (T)vmf_log_norm_f32(dim, (float)kap);
+    else out[i] = (T)vmf_log_norm(dim, (double)kap);
   }
 }
 
@@ -656,11 +682,13 @@ static bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 template <typename T>
 static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, void* z,
-                         void* w_out, void* omw_out, int32_t* accept_idx, void* logp_out, int64_t n, int m,
-                         const void* prop_e, const void* prop_u, int n_prop, const void* gauss, int max_prop,
+                         void* w_out, void* omw_out, int32_t* accept_idx, void* logp_out, void* kappa_out, int64_t n,
+                         int m, const void* prop_e, const void* prop_u, int n_prop, const void* gauss, int max_prop,
                          uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int flags,
                          hipStream_t s) {
   FwdParams<T> p = {};
+  p.kappa_out = (T*)kappa_out;
+  p.softplus = (flags & VMF_FLAG_SOFTPLUS_KAPPA) ? 1 : 0;
   p.mu = (const T*)mu; p.kappa = (const T*)kappa; p.z = (T*)z;
   p.w_out = (T*)w_out; p.omw_out = (T*)omw_out; p.accept_idx = accept_idx; p.logp = (T*)logp_out;
   p.prop_e = (const T*)prop_e; p.prop_u = (const T*)prop_u; p.gauss = (const T*)gauss;
@@ -689,25 +717,28 @@ static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   }
   if (logp_out && sizeof(T) == 8)
     hipLaunchKernelGGL(vmf_log_norm_kernel<T>, dim3(vmf_grid_for(n, 256)), dim3(256), 0, s, (const T*)kappa,
-                       kappa_stride, (T*)logp_out, n, make_vmf_dim(m));
+                       kappa_stride, (T*)logp_out, n, make_vmf_dim(m), p.softplus);
   const bool pair_ok = m == 2 && !prop_e && !gauss && mu_stride % 2 == 0 && ((uintptr_t)mu % (2 * sizeof(T))) == 0 &&
                        ((uintptr_t)z % (2 * sizeof(T))) == 0;
   if (pair_ok) {
     const int64_t nt = (n + VMF_TILE_ROWS_CIRCLE - 1) / VMF_TILE_ROWS_CIRCLE;
     hipLaunchKernelGGL((vmf_rsample_fwd_kernel<T, 1, 1, 3>), dim3((unsigned)((nt + WAVES - 1) / WAVES)), dim3(WAVES * 64), 0,
                        s, p);
-  } else if (full && !prop_e && !p.normalize) launch_fwd<T, 2>(p, grid, s);
+  } else if (full && !prop_e && !p.normalize && !p.softplus && !kappa_out) launch_fwd<T, 2>(p, grid, s);
   else if (vec) launch_fwd<T, 1>(p, grid, s);
   else launch_fwd<T, 0>(p, grid, s);
   return VMF_OK;
 }
 
 extern "C" int vmf_rsample_fwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, void* z,
-                               void* w_out, void* omw_out, int32_t* accept_idx, void* logp_out, int64_t n, int m,
-                               const void* prop_e, const void* prop_u, int n_prop, const void* gauss, int max_prop,
-                               uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int flags,
-                               int dtype, vmf_stream_t stream) {
+                               void* w_out, void* omw_out, int32_t* accept_idx, void* logp_out, void* kappa_out,
+                               int64_t n, int m, const void* prop_e, const void* prop_u, int n_prop, const void* gauss,
+                               int max_prop, uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                               int flags, int dtype, vmf_stream_t stream) {
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
+  VMF_REQUIRE((flags & ~(VMF_FLAG_NORMALIZE_MU | VMF_FLAG_SOFTPLUS_KAPPA)) == 0, VMF_ERR_BAD_ARG,
+              "vmf_rsample_fwd: unknown flags %d", flags);
+  VMF_REQUIRE(!kappa_out || kappa_stride == 1, VMF_ERR_BAD_ARG, "vmf_rsample_fwd: kappa_out needs kappa_stride 1");
   VMF_REQUIRE(m >= 2, VMF_ERR_BAD_ARG, "m=%d < 2", m);
   VMF_REQUIRE(m <= 2048, VMF_ERR_UNSUPPORTED, "m=%d > 2048 is not supported", m);
   VMF_REQUIRE(mu_stride == 0 || mu_stride >= m, VMF_ERR_BAD_ARG, "mu_stride=%lld", (long long)mu_stride);
@@ -723,7 +754,7 @@ extern "C" int vmf_rsample_fwd(const void* mu, int64_t mu_stride, const void* ka
   VMF_REQUIRE(mu && kappa && z, VMF_ERR_BAD_ARG, "vmf_rsample_fwd: null mu/kappa/z");
   int rc;
   VMF_DISPATCH_DTYPE(dtype, rc = rsample_fwd_t<T>(mu, mu_stride, kappa, kappa_stride, z, w_out, omw_out, accept_idx,
-                                                  logp_out, n, m, prop_e, prop_u, n_prop, gauss, max_prop, row0,
+                                                  logp_out, kappa_out, n, m, prop_e, prop_u, n_prop, gauss, max_prop, row0,
                                                   seed, offset, offset_dev, flags, (hipStream_t)stream));
   if (rc) return rc;
   return vmf_check_launch("vmf_rsample_fwd");
@@ -731,10 +762,12 @@ extern "C" int vmf_rsample_fwd(const void* mu, int64_t mu_stride, const void* ka
 
 template <typename T>
 static int rsample_bwd_t(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, const void* w,
-                         const void* omw, const void* gz, const void* gauss, void* dmu, void* dkappa, int64_t n,
-                         int m, uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int flags,
-                         hipStream_t s) {
+                         const void* omw, const void* gz, const void* gauss, const void* gkappa, void* dmu,
+                         void* dkappa, int64_t n, int m, uint64_t row0, uint64_t seed, uint64_t offset,
+                         const uint64_t* offset_dev, int flags, hipStream_t s) {
   GenParams<T> p = {};
+  p.softplus = (flags & VMF_FLAG_SOFTPLUS_KAPPA) ? 1 : 0;
+  p.gkappa = (const T*)gkappa;
   p.normalize = (flags & VMF_FLAG_NORMALIZE_MU) ? 1 : 0;
   p.mu = (const T*)mu; p.mu_stride = mu_stride; p.kappa = (const T*)kappa; p.kappa_stride = kappa_stride;
   p.gauss = (const T*)gauss; p.n = n; p.m = m; p.row0 = row0; p.ka = make_philox_arg(seed, offset, offset_dev);
@@ -759,10 +792,14 @@ static int rsample_bwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
 }
 
 extern "C" int vmf_rsample_bwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride,
-                               const void* w, const void* omw, const void* grad_z, const void* gauss, void* dmu,
-                               void* dkappa, int64_t n, int m, uint64_t row0, uint64_t seed, uint64_t offset,
-                               const uint64_t* offset_dev, int flags, int dtype, vmf_stream_t stream) {
+                               const void* w, const void* omw, const void* grad_z, const void* gauss,
+                               const void* grad_kappa, void* dmu, void* dkappa, int64_t n, int m, uint64_t row0,
+                               uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int flags, int dtype,
+                               vmf_stream_t stream) {
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
+  VMF_REQUIRE((flags & ~(VMF_FLAG_NORMALIZE_MU | VMF_FLAG_SOFTPLUS_KAPPA)) == 0, VMF_ERR_BAD_ARG,
+              "vmf_rsample_bwd: unknown flags %d", flags);
+  VMF_REQUIRE(!grad_kappa || kappa_stride == 1, VMF_ERR_BAD_ARG, "vmf_rsample_bwd: grad_kappa needs kappa_stride 1");
   VMF_REQUIRE(m >= 2, VMF_ERR_BAD_ARG, "m=%d < 2", m);
   VMF_REQUIRE(m <= 2048, VMF_ERR_UNSUPPORTED, "m=%d > 2048 is not supported", m);
   VMF_REQUIRE(mu_stride == 0 || mu_stride >= m, VMF_ERR_BAD_ARG, "mu_stride=%lld", (long long)mu_stride);
@@ -770,8 +807,9 @@ extern "C" int vmf_rsample_bwd(const void* mu, int64_t mu_stride, const void* ka
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(mu && kappa && w && grad_z && dmu && dkappa, VMF_ERR_BAD_ARG, "vmf_rsample_bwd: null pointer");
   int rc;
-  VMF_DISPATCH_DTYPE(dtype, rc = rsample_bwd_t<T>(mu, mu_stride, kappa, kappa_stride, w, omw, grad_z, gauss, dmu,
-                                                  dkappa, n, m, row0, seed, offset, offset_dev, flags, (hipStream_t)stream));
+  VMF_DISPATCH_DTYPE(dtype, rc = rsample_bwd_t<T>(mu, mu_stride, kappa, kappa_stride, w, omw, grad_z, gauss, grad_kappa,
+                                                  dmu, dkappa, n, m, row0, seed, offset, offset_dev, flags,
+                                                  (hipStream_t)stream));
   if (rc) return rc;
   return vmf_check_launch("vmf_rsample_bwd");
 }

@@ -9,7 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..sampler.spherical_uniform import HypersphericalUniform
-from ..sampler.von_mises_fisher import VonMisesFisher
+from ..sampler.von_mises_fisher import VonMisesFisher, vmf_rsample_from_heads
 
 
 class HypersphericalVAE(nn.Module):
@@ -49,16 +49,15 @@ class HypersphericalVAE(nn.Module):
         return self.function_x_mu(h)
 
     def forward(self, x):
-        """encode -> sample -> decode.  The sampler takes the raw output of the mean head and normalises it inside its
-        kernels (forward and backward), so the (B, latent_dim) tensor is not read and rewritten by a separate
-        normalisation pass; the posterior parameters returned are the same (unit z_mu, kappa) that encode() gives."""
+        """encode -> sample -> decode.  The sampler takes the raw outputs of BOTH heads: it normalises the mean rows and
+        evaluates kappa = softplus(.) + 1 inside its kernels (forward and backward), so neither the (B, latent_dim)
+        normalisation pass nor the softplus / add passes and their backward launches exist; the posterior parameters
+        returned are the same (unit z_mu, kappa) that encode() gives."""
         h = F.softplus(self.encoder_function(x), beta=self.sftbeta)
         for layer in self.encoder_linear_layers:
             h = F.softplus(layer(h), beta=self.sftbeta)
         raw = self.function_z_mu(h)
-        z_kappa = F.softplus(self.function_z_logvar(h)).squeeze(-1) + 1
-        q_z = VonMisesFisher(raw, z_kappa, validate_args=False, normalize_loc=True)
-        z = q_z.rsample()
+        z, z_kappa = vmf_rsample_from_heads(raw, self.function_z_logvar(h).squeeze(-1))
         with torch.no_grad():  # reporting only: the KL term depends on kappa alone
             z_mu = F.normalize(raw, dim=-1)
         return z, self.decode(z), (z_mu, z_kappa)

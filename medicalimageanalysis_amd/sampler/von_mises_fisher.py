@@ -18,7 +18,7 @@ from .ive import ive
 from .spherical_uniform import HypersphericalUniform
 
 __all__ = ["math", "torch", "ive", "Distribution", "constraints", "VonMisesFisher3D", "VonMisesFisher3DLogProb",
-           "VonMisesFisher", "HypersphericalUniform", "vmf3_rsample_from_heads"]
+           "VonMisesFisher", "HypersphericalUniform", "vmf3_rsample_from_heads", "vmf_rsample_from_heads"]
 
 _MAX_DIMS = 8
 
@@ -385,6 +385,9 @@ class VonMisesFisher3DLogProb(VonMisesFisher3D):
 
 # ---- general m ---------------------------------------------------------------------------------------------
 class _VMFRSample(torch.autograd.Function):
+    """returns z, then log p(z) if want_logp, then kappa if flags has FLAG_SOFTPLUS_KAPPA (`kappa` then holds the raw head
+    output and the returned kappa = softplus(raw) + 1 is differentiable through the same backward launch)"""
+
     @staticmethod
     def forward(ctx, mu, kappa, n, mu_stride, kappa_stride, max_prop, row0, seed, offset, want_logp, offset_dev=None,
                 flags=0):
@@ -395,40 +398,64 @@ class _VMFRSample(torch.autograd.Function):
         w = torch.empty((n,), device=dev, dtype=mu.dtype)
         omw = torch.empty((n,), device=dev, dtype=mu.dtype)
         logp = torch.empty((n,), device=dev, dtype=mu.dtype) if want_logp else None
+        soft = bool(flags & _lib.FLAG_SOFTPLUS_KAPPA)
+        kout = torch.empty((n,), device=dev, dtype=mu.dtype) if soft else None
         with torch.cuda.device(dev):
             rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(muc), mu_stride, _lib.ptr(kc), kappa_stride, _lib.ptr(z),
-                                            _lib.ptr(w), _lib.ptr(omw), None, _lib.ptr(logp), n, m, None, None, 0,
-                                            None, max_prop, row0, seed, offset, _lib.ptr(offset_dev), flags,
-                                            _lib.dtype_code(muc),
-                                            _lib.stream_ptr(dev))
+                                            _lib.ptr(w), _lib.ptr(omw), None, _lib.ptr(logp), _lib.ptr(kout), n, m, None,
+                                            None, 0, None, max_prop, row0, seed, offset, _lib.ptr(offset_dev), flags,
+                                            _lib.dtype_code(muc), _lib.stream_ptr(dev))
         _lib.check(rc, "vmf_rsample_fwd")
         ctx.save_for_backward(muc, kc, w, omw)
         ctx.meta = (n, m, mu_stride, kappa_stride, row0, seed, offset, mu.shape, kappa.shape)
-        ctx.offset_dev, ctx.flags = offset_dev, flags
+        ctx.offset_dev, ctx.flags, ctx.want_logp = offset_dev, flags, want_logp
+        out = (z,)
         if want_logp:
             ctx.mark_non_differentiable(logp)
-            return z, logp
-        return z
+            out += (logp,)
+        if soft:
+            out += (kout,)
+        return out if len(out) > 1 else z
 
     @staticmethod
-    def backward(ctx, gz, *unused):
+    def backward(ctx, gz, *rest):
         muc, kc, w, omw = ctx.saved_tensors
         n, m, mu_stride, kappa_stride, row0, seed, offset, mu_shape, k_shape = ctx.meta
         dev = muc.device
         gzc = gz.to(muc.dtype).contiguous()
+        gk = rest[-1] if (ctx.flags & _lib.FLAG_SOFTPLUS_KAPPA) and rest else None
+        gkc = None if gk is None else gk.to(muc.dtype).contiguous()
         dmu = torch.empty((n, m), device=dev, dtype=muc.dtype)
         dk = torch.empty((n,), device=dev, dtype=muc.dtype)
         with torch.cuda.device(dev):
             rc = _lib.lib().vmf_rsample_bwd(_lib.ptr(muc), mu_stride, _lib.ptr(kc), kappa_stride, _lib.ptr(w),
-                                            _lib.ptr(omw), _lib.ptr(gzc), None, _lib.ptr(dmu), _lib.ptr(dk), n, m,
-                                            row0, seed, offset, _lib.ptr(ctx.offset_dev), ctx.flags, _lib.dtype_code(muc),
-                                            _lib.stream_ptr(dev))
+                                            _lib.ptr(omw), _lib.ptr(gzc), None, _lib.ptr(gkc), _lib.ptr(dmu), _lib.ptr(dk),
+                                            n, m, row0, seed, offset, _lib.ptr(ctx.offset_dev), ctx.flags,
+                                            _lib.dtype_code(muc), _lib.stream_ptr(dev))
         _lib.check(rc, "vmf_rsample_bwd")
         if mu_stride == 0:
             dmu = dmu.sum(0, keepdim=True)
         if kappa_stride == 0:
             dk = dk.sum(0, keepdim=True)
         return (dmu.view(mu_shape), dk.view(k_shape)) + (None,) * 10
+
+
+def vmf_rsample_from_heads(loc_raw, scale_raw, generator=None, row_offset=0, max_proposals=64):
+    """(z, kappa) on S^{m-1} straight from the two encoder heads: loc_raw (B, m) is the un-normalised output of the mean
+    head, scale_raw (B,) or (B, 1) the raw output of the concentration head.  The sampler kernels normalise the mean
+    rows and evaluate kappa = softplus(scale_raw) + 1 (the head of model/spherical_vae.py:68-72) themselves, forward and
+    backward; kappa comes back for the KL term with its gradient routed through the same backward launch.  One sample
+    per row (z is (B, m))."""
+    assert loc_raw.dim() == 2 and loc_raw.shape[-1] >= 2, "vmf_rsample_from_heads: loc_raw must be (B, m), m >= 2"
+    n, m = loc_raw.shape
+    raw = scale_raw.to(loc_raw.dtype).reshape(n)
+    gen = generator or rng.default_generator
+    seed, offset, offset_dev = gen.ticket(loc_raw.device)
+    if n == 0:
+        return loc_raw.new_empty((0, m)), raw.new_empty((0,)).view(scale_raw.shape)
+    z, kappa = _VMFRSample.apply(loc_raw, raw, n, m, 1, int(max_proposals), int(row_offset), seed, offset, False,
+                                 offset_dev, _lib.FLAG_NORMALIZE_MU | _lib.FLAG_SOFTPLUS_KAPPA)
+    return z, kappa.view(scale_raw.shape)
 
 
 class _VMFLogProb(torch.autograd.Function):

@@ -683,7 +683,7 @@ def _call_rsample_pre(mu, kappa, pe, pu, ga, dtype):
     w = torch.empty(n, device=DEV, dtype=dtype)
     idx = torch.empty(n, device=DEV, dtype=torch.int32)
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(tmu), m, _lib.ptr(tk), 1, _lib.ptr(z), _lib.ptr(w), None,
-                                    C.c_void_p(idx.data_ptr()), None, n, m, _lib.ptr(tpe), _lib.ptr(tpu), pe.shape[1],
+                                    C.c_void_p(idx.data_ptr()), None, None, n, m, _lib.ptr(tpe), _lib.ptr(tpu), pe.shape[1],
                                     _lib.ptr(tga), 0, 0, 0, 0, None, 0, _lib.dtype_code(z), _lib.stream_ptr(DEV))
     _lib.check(rc, "vmf_rsample_fwd")
     torch.cuda.synchronize()
@@ -728,7 +728,7 @@ def test_general_rsample_philox_vs_oracle(oracle, tag, m, n):
     w = torch.empty(n, device=DEV, dtype=TD[tag])
     idx = torch.empty(n, device=DEV, dtype=torch.int32)
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(tmu), m, _lib.ptr(tk), 1, _lib.ptr(z), _lib.ptr(w), None,
-                                    C.c_void_p(idx.data_ptr()), None, n, m, None, None, 0, None, 64, row0, seed, off, None, 0,
+                                    C.c_void_p(idx.data_ptr()), None, None, n, m, None, None, 0, None, 64, row0, seed, off, None, 0,
                                     _lib.dtype_code(z), _lib.stream_ptr(DEV))
     _lib.check(rc, "vmf_rsample_fwd")
     z, w, idx = N(z), N(w), N(idx)
@@ -742,7 +742,7 @@ def test_general_rsample_philox_vs_oracle(oracle, tag, m, n):
     a, b = n // 3, n // 3 + min(777, n // 2)
     z2 = torch.empty((b - a, m), device=DEV, dtype=TD[tag])
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(tmu[a:b].contiguous()), m, _lib.ptr(tk[a:b].contiguous()), 1,
-                                    _lib.ptr(z2), None, None, None, None, b - a, m, None, None, 0, None, 64, row0 + a,
+                                    _lib.ptr(z2), None, None, None, None, None, b - a, m, None, None, 0, None, 64, row0 + a,
                                     seed, off, None, 0, _lib.dtype_code(z2), _lib.stream_ptr(DEV))
     _lib.check(rc, "vmf_rsample_fwd shard")
     assert np.array_equal(N(z2), z[a:b])
@@ -756,7 +756,7 @@ def test_general_rsample_philox_vs_oracle(oracle, tag, m, n):
         assert mu_off.data_ptr() % (2 * es) == es
         idx3 = torch.empty(n, device=DEV, dtype=torch.int32)
         rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(mu_off), m, _lib.ptr(tk), 1, _lib.ptr(z_off), None, None,
-                                        C.c_void_p(idx3.data_ptr()), None, n, m, None, None, 0, None, 64, row0, seed, off,
+                                        C.c_void_p(idx3.data_ptr()), None, None, n, m, None, None, 0, None, 64, row0, seed, off,
                                         None, 0, _lib.dtype_code(z_off), _lib.stream_ptr(DEV))
         _lib.check(rc, "vmf_rsample_fwd unaligned")
         assert np.array_equal(N(idx3), idx)
@@ -817,7 +817,7 @@ def test_general_rsample_every_row_written_once_for_any_grid(m):
         mu = torch.nn.functional.normalize(torch.randn(n, m, device=DEV, generator=g), dim=-1)
         kappa = torch.exp(torch.rand(n, device=DEV, generator=g) * np.log(1e3))
         z = torch.full((n, m), float("nan"), device=DEV)
-        _lib.check(lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(z), None, None, None, None, n, m, None,
+        _lib.check(lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(z), None, None, None, None, None, n, m, None,
                                        None, 0, None, 64, 0, 7, 3, None, 0, _lib.VMF_F32, sp), "vmf_rsample_fwd")
         assert bool(torch.isfinite(z).all()), (m, nb)
         assert float((z.norm(dim=-1) - 1).abs().max()) < 1e-4
@@ -826,7 +826,7 @@ def test_general_rsample_every_row_written_once_for_any_grid(m):
         for a0, b0 in ((0, cut), (cut, n)):
             zp = torch.full((b0 - a0, m), float("nan"), device=DEV)
             _lib.check(lib.vmf_rsample_fwd(_lib.ptr(mu[a0:b0]), m, _lib.ptr(kappa[a0:b0]), 1, _lib.ptr(zp), None, None, None,
-                                           None, b0 - a0, m, None, None, 0, None, 64, a0, 7, 3, None, 0, _lib.VMF_F32, sp),
+                                           None, None, b0 - a0, m, None, None, 0, None, 64, a0, 7, 3, None, 0, _lib.VMF_F32, sp),
                        "vmf_rsample_fwd shard")
             parts.append(zp)
         assert torch.equal(torch.cat(parts), z), (m, nb)
@@ -845,13 +845,13 @@ def test_general_backward_writes_every_row_for_any_size(m):
         gz = torch.randn(n, m, device=DEV, generator=g)
         z, w, omw = torch.empty_like(mu), torch.empty_like(kappa), torch.empty_like(kappa)
         _lib.check(lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(z), _lib.ptr(w), _lib.ptr(omw), None,
-                                       None, n, m, None, None, 0, None, 64, 0, 7, 3, None, 0, _lib.VMF_F32, sp), "fwd")
+                                       None, None, n, m, None, None, 0, None, 64, 0, 7, 3, None, 0, _lib.VMF_F32, sp), "fwd")
 
         def bwd(k):
             dmu = torch.full((k, m), float("nan"), device=DEV)
             dk = torch.full((k,), float("nan"), device=DEV)
             _lib.check(lib.vmf_rsample_bwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(w), _lib.ptr(omw), _lib.ptr(gz), None,
-                                           _lib.ptr(dmu), _lib.ptr(dk), k, m, 0, 7, 3, None, 0, _lib.VMF_F32, sp), "bwd")
+                                           None, _lib.ptr(dmu), _lib.ptr(dk), k, m, 0, 7, 3, None, 0, _lib.VMF_F32, sp), "bwd")
             return dmu, dk
 
         dmu, dk = bwd(n)
@@ -872,7 +872,7 @@ def test_general_rsample_full_size_properties():
     w = torch.empty(n, device=DEV)
     idx = torch.empty(n, device=DEV, dtype=torch.int32)
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(z), _lib.ptr(w), None,
-                                    C.c_void_p(idx.data_ptr()), None, n, m, None, None, 0, None, 64, 0, 99, 0, None, 0,
+                                    C.c_void_p(idx.data_ptr()), None, None, n, m, None, None, 0, None, 64, 0, 99, 0, None, 0,
                                     _lib.VMF_F32, _lib.stream_ptr(DEV))
     _lib.check(rc, "vmf_rsample_fwd")
     assert float((z.norm(dim=-1) - 1).abs().max()) < 1e-4
@@ -885,7 +885,7 @@ def test_general_rsample_full_size_properties():
     a = n - 1000
     z2 = torch.empty((1000, m), device=DEV)
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(mu[a:]), m, _lib.ptr(kappa[a:]), 1, _lib.ptr(z2), None, None, None, None,
-                                    1000, m, None, None, 0, None, 64, a, 99, 0, None, 0, _lib.VMF_F32, _lib.stream_ptr(DEV))
+                                    None, 1000, m, None, None, 0, None, 64, a, 99, 0, None, 0, _lib.VMF_F32, _lib.stream_ptr(DEV))
     _lib.check(rc, "vmf_rsample_fwd")
     assert torch.equal(z2, z[a:])
 
@@ -1027,6 +1027,45 @@ def test_general_rsample_normalises_raw_mean_inside_the_kernel(tag, m):
     np.testing.assert_allclose(N(qa.log_prob(za.detach())), N(qb.log_prob(za.detach())), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("m", [10, 64])
+def test_general_softplus_fold_matches_torch_softplus(tag, m):
+    """both encoder heads raw into the general-m sampler (normalisation and kappa = softplus(.) + 1 inside the kernels,
+    model/spherical_vae.py:68-72) against torch ops in front of the plain call: z, the returned kappa, gradients of a
+    loss that uses both"""
+    from medicalimageanalysis_amd.sampler.von_mises_fisher import vmf_rsample_from_heads
+    dt = TD[tag]
+    g = torch.Generator(device=DEV).manual_seed(40 + m)
+    n = 3000
+    raw_mu = torch.randn(n, m, device=DEV, generator=g, dtype=dt) * 3
+    raw_k = torch.rand(n, 1, device=DEV, generator=g, dtype=dt) * 30 - 5
+    ma, ka = raw_mu.clone().requires_grad_(), raw_k.clone().requires_grad_()
+    mb, kb = raw_mu.clone().requires_grad_(), raw_k.clone().requires_grad_()
+    z, kap = vmf_rsample_from_heads(ma, ka, generator=rng.PhiloxGenerator(7, 3))
+    kap_ref = torch.nn.functional.softplus(kb) + 1
+    z_ref = VonMisesFisher(mb, kap_ref, validate_args=False, normalize_loc=True,
+                           generator=rng.PhiloxGenerator(7, 3)).rsample()
+    assert z.shape == (n, m) and kap.shape == (n, 1)
+    c = torch.randn(n, m, device=DEV, generator=g, dtype=dt)
+    d = torch.randn(n, 1, device=DEV, generator=g, dtype=dt)
+    ((z * c).sum() + (kap * d).sum()).backward()
+    ((z_ref * c).sum() + (kap_ref * d).sum()).backward()
+    if tag == "f64":
+        np.testing.assert_allclose(N(kap), N(kap_ref), rtol=1e-14)
+        np.testing.assert_allclose(N(z), N(z_ref), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(N(ma.grad), N(mb.grad), rtol=1e-8, atol=1e-9 * float(mb.grad.abs().max()))
+        np.testing.assert_allclose(N(ka.grad), N(kb.grad), rtol=1e-8, atol=1e-9 * float(kb.grad.abs().max()))
+    else:
+        np.testing.assert_allclose(N(kap), N(kap_ref), rtol=2e-6)
+        # kappa differs in its last bit on some rows: a borderline proposal may then be accepted one step apart
+        same = (N(z) - N(z_ref)).__abs__().max(axis=1) < 1e-4
+        assert same.mean() > 0.995, same.mean()
+        ga, gb = N(ma.grad)[same], N(mb.grad)[same]
+        np.testing.assert_allclose(ga, gb, rtol=5e-3, atol=5e-3 * np.abs(gb).max())
+        ka_, kb_ = N(ka.grad)[same], N(kb.grad)[same]
+        np.testing.assert_allclose(ka_, kb_, rtol=5e-3, atol=5e-3 * np.abs(kb_).max())
+
+
 def test_circle_counter_noise_backward_regenerates_the_forward_sign():
     """m = 2 with in-kernel noise: two proposals per Philox call and a one-bit tangent.  The backward pass
     regenerates that bit; check it against autograd through the forward restated in torch with the accepted proposal
@@ -1093,13 +1132,13 @@ def test_general_backward_vs_autograd_of_restated_forward(m):
     omw = torch.empty(n, device=DEV, dtype=torch.float64)
     mud, kd = mu.detach().contiguous(), kappa.detach().contiguous()
     rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(mud), m, _lib.ptr(kd), 1, _lib.ptr(zk), _lib.ptr(w), _lib.ptr(omw), None,
-                                    None, n, m, _lib.ptr(pe), _lib.ptr(pu), 4, _lib.ptr(ga), 0, 0, 0, 0, None, 0, _lib.VMF_F64,
+                                    None, None, n, m, _lib.ptr(pe), _lib.ptr(pu), 4, _lib.ptr(ga), 0, 0, 0, 0, None, 0, _lib.VMF_F64,
                                     _lib.stream_ptr(DEV))
     _lib.check(rc, "fwd")
     dmu = torch.empty_like(mud)
     dk = torch.empty_like(kd)
     rc = _lib.lib().vmf_rsample_bwd(_lib.ptr(mud), m, _lib.ptr(kd), 1, _lib.ptr(w), _lib.ptr(omw), _lib.ptr(c),
-                                    _lib.ptr(ga), _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 0, 0, None, 0, _lib.VMF_F64,
+                                    _lib.ptr(ga), None, _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 0, 0, None, 0, _lib.VMF_F64,
                                     _lib.stream_ptr(DEV))
     _lib.check(rc, "bwd")
     mu2, k2 = mud.clone().requires_grad_(), kd.clone().requires_grad_()
@@ -1142,11 +1181,11 @@ def test_general_fp32_draws_and_gradients_agree_with_fp64(m):
         idx = torch.empty(n, device=DEV, dtype=torch.int32)
         code = _lib.dtype_code(a)
         _lib.check(lib.vmf_rsample_fwd(_lib.ptr(a), m, _lib.ptr(k), 1, _lib.ptr(z), _lib.ptr(w), _lib.ptr(omw),
-                                       C.c_void_p(idx.data_ptr()), None, n, m, None, None, 0, None, 64, 0, 5, 9, None, 0,
+                                       C.c_void_p(idx.data_ptr()), None, None, n, m, None, None, 0, None, 64, 0, 5, 9, None, 0,
                                        code, sp), "vmf_rsample_fwd")
         dmu, dk = torch.empty_like(a), torch.empty_like(k)
         _lib.check(lib.vmf_rsample_bwd(_lib.ptr(a), m, _lib.ptr(k), 1, _lib.ptr(w), _lib.ptr(omw), _lib.ptr(c), None,
-                                       _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 5, 9, None, 0, code, sp), "vmf_rsample_bwd")
+                                       None, _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 5, 9, None, 0, code, sp), "vmf_rsample_bwd")
         return z.double(), idx, dmu.double(), dk.double()
 
     z32, i32, dm32, dk32 = run(torch.float32)
@@ -1178,7 +1217,7 @@ def test_general_m3_fp32_keeps_its_digits_at_the_south_pole():
         z, w = torch.empty_like(a), torch.empty_like(k)
         idx = torch.empty(n, device=DEV, dtype=torch.int32)
         _lib.check(lib.vmf_rsample_fwd(_lib.ptr(a), m, _lib.ptr(k), 1, _lib.ptr(z), _lib.ptr(w), None,
-                                       C.c_void_p(idx.data_ptr()), None, n, m, None, None, 0, None, 64, 0, 11, 3, None, 0,
+                                       C.c_void_p(idx.data_ptr()), None, None, n, m, None, None, 0, None, 64, 0, 11, 3, None, 0,
                                        _lib.dtype_code(a), sp), "vmf_rsample_fwd")
         return z.double(), w.double(), idx
 
@@ -1624,7 +1663,7 @@ def test_error_conventions():
         VonMisesFisher3D(loc.half(), torch.ones(4, device=DEV).half(), validate_args=False).rsample()
     z = VonMisesFisher3D(torch.randn(0, 3, device=DEV), torch.ones(0, device=DEV)).rsample()
     assert z.shape == (0, 3)
-    rc = _lib.lib().vmf_rsample_fwd(None, 64, None, 1, None, None, None, None, None, 10, 64, None, None, 0, None, 64, 0,
+    rc = _lib.lib().vmf_rsample_fwd(None, 64, None, 1, None, None, None, None, None, None, 10, 64, None, None, 0, None, 64, 0,
                                     0, 0, None, 0, 0, None)
     assert rc == -1 and b"null" in _lib.lib().vmf_last_error_string()
     rc = _lib.lib().vmf_ive_fwd(0.5, _lib.ptr(loc), _lib.ptr(loc), 4, 7, None)

@@ -26,10 +26,10 @@ def test_abi_exports_every_declared_symbol():
     lib = _lib.lib()
     assert lib.vmf_version() == 130
     # argument errors are reported without touching a GPU
-    assert lib.vmf_rsample_fwd(None, 64, None, 1, None, None, None, None, None, -1, 64, None, None, 0, None, 64, 0, 0, 0, None, 0,
+    assert lib.vmf_rsample_fwd(None, 64, None, 1, None, None, None, None, None, None, -1, 64, None, None, 0, None, 64, 0, 0, 0, None, 0,
                                0, None) == -1
     assert b"n < 0" in lib.vmf_last_error_string()
-    assert lib.vmf_rsample_fwd(None, 64, None, 1, None, None, None, None, None, 5, 4096, None, None, 0, None, 64, 0, 0, 0, None, 0,
+    assert lib.vmf_rsample_fwd(None, 64, None, 1, None, None, None, None, None, None, 5, 4096, None, None, 0, None, 64, 0, 0, 0, None, 0,
                                0, None) == -4
     assert lib.vmf_kl_fwd(None, None, None, None, 1.0, 0, 99, 0, None) == -1
 

@@ -49,7 +49,7 @@ if a.kernel.startswith("s1"):
     dmu = torch.empty_like(mu)
 elif a.kernel != "fwd":
     rc = hs[0][1].vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(z), _lib.ptr(w), _lib.ptr(omw), None, None,
-                                  n, m, None, None, 0, None, 64, 0, 0x5EED, 0, None, 0, _lib.VMF_F32, sp)
+                                  None, n, m, None, None, 0, None, 64, 0, 0x5EED, 0, None, 0, _lib.VMF_F32, sp)
     assert rc == 0
     gz = torch.randn(n, m, device=dev)
     dmu = torch.empty_like(mu)
@@ -69,14 +69,14 @@ def step(h, i):
         return
     if a.kernel == "bwd":
         rc = h.vmf_rsample_bwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(w), _lib.ptr(omw), _lib.ptr(gz), None,
-                               _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 0x5EED, 0, None, 0, _lib.VMF_F32, sp)
+                               None, _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 0x5EED, 0, None, 0, _lib.VMF_F32, sp)
         assert rc == 0, rc
         return
     if a.kernel == "logprob":
         rc = h.vmf_log_prob_fwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(z), _lib.ptr(logp), n, m, _lib.VMF_F32, sp)
         assert rc == 0, rc
         return
-    rc = h.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(z), None, None, None, _lib.ptr(logp), n, m, None,
+    rc = h.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(z), None, None, None, _lib.ptr(logp), None, n, m, None,
                            None, 0, None, 64, 0, 0x5EED, i, None, 0, _lib.VMF_F32, sp)
     assert rc == 0, rc
 

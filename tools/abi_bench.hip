@@ -59,14 +59,14 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(fill_kappa, dim3(2048), dim3(256), 0, stream, kappa, n, logf(1e4f));
   HIP_OK(hipGetLastError());
   for (int i = 0; i < warmup; ++i)
-    VMF_OK_(vmf_rsample_fwd(mu, m, kappa, 1, z, nullptr, nullptr, nullptr, logp, n, m, nullptr, nullptr, 0, nullptr, 64,
+    VMF_OK_(vmf_rsample_fwd(mu, m, kappa, 1, z, nullptr, nullptr, nullptr, logp, nullptr, n, m, nullptr, nullptr, 0, nullptr, 64,
                             0, 0x5EED, (uint64_t)i, nullptr, 0, VMF_F32, stream));
   HIP_OK(hipStreamSynchronize(stream));
   std::vector<hipEvent_t> ev(2 * steps);
   for (auto& e : ev) HIP_OK(hipEventCreate(&e));
   for (int i = 0; i < steps; ++i) {
     HIP_OK(hipEventRecord(ev[2 * i], stream));
-    VMF_OK_(vmf_rsample_fwd(mu, m, kappa, 1, z, nullptr, nullptr, nullptr, logp, n, m, nullptr, nullptr, 0, nullptr, 64,
+    VMF_OK_(vmf_rsample_fwd(mu, m, kappa, 1, z, nullptr, nullptr, nullptr, logp, nullptr, n, m, nullptr, nullptr, 0, nullptr, 64,
                             0, 0x5EED, (uint64_t)(warmup + i), nullptr, 0, VMF_F32, stream));
     HIP_OK(hipEventRecord(ev[2 * i + 1], stream));
   }

@@ -54,7 +54,7 @@ def main():
         es = 4 if dt == torch.float32 else 8
 
         def f():
-            rc = lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(z), None, None, None, _lib.ptr(lp), n, m,
+            rc = lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(z), None, None, None, _lib.ptr(lp), None, n, m,
                                      None, None, 0, None, 64, 0, 1, 0, None, 0, _lib.dtype_code(mu), sp)
             assert rc == 0
         ms = timeit(f)
@@ -63,7 +63,7 @@ def main():
         if m == 64 and dt == torch.float32:
             w = torch.empty(n, device=DEV)
             omw = torch.empty(n, device=DEV)
-            lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(z), _lib.ptr(w), _lib.ptr(omw), None, None, n, m,
+            lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(z), _lib.ptr(w), _lib.ptr(omw), None, None, None, n, m,
                                 None, None, 0, None, 64, 0, 1, 0, None, 0, _lib.VMF_F32, sp)
             gz = torch.randn_like(mu)
             dmu = torch.empty_like(mu)
@@ -71,7 +71,7 @@ def main():
 
             def fb():
                 rc = lib.vmf_rsample_bwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(w), _lib.ptr(omw), _lib.ptr(gz), None,
-                                         _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 1, 0, None, 0, _lib.VMF_F32, sp)
+                                         None, _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 1, 0, None, 0, _lib.VMF_F32, sp)
                 assert rc == 0
             ms = timeit(fb)
             row("rsample bwd m=64 n=2^24 float32 (noise regenerated)", ms, n * (3 * m + 3) * 4, n, "rows")
@@ -89,7 +89,7 @@ def main():
         z = torch.empty(n, m, device=DEV)
 
         def fs():
-            rc = lib.vmf_rsample_fwd(_lib.ptr(mu1), 0, _lib.ptr(k1), 0, _lib.ptr(z), None, None, None, None, n, m, None, None,
+            rc = lib.vmf_rsample_fwd(_lib.ptr(mu1), 0, _lib.ptr(k1), 0, _lib.ptr(z), None, None, None, None, None, n, m, None, None,
                                      0, None, 64, 0, 1, 0, None, 0, _lib.VMF_F32, sp)
             assert rc == 0
         ms = timeit(fs)
@@ -256,7 +256,7 @@ def main():
     z = torch.empty_like(mu)
 
     def f5():
-        rc = lib.vmf_rsample_fwd(_lib.ptr(mu), 2, _lib.ptr(kap), 1, _lib.ptr(z), None, None, None, None, n, 2, None, None,
+        rc = lib.vmf_rsample_fwd(_lib.ptr(mu), 2, _lib.ptr(kap), 1, _lib.ptr(z), None, None, None, None, None, n, 2, None, None,
                                  0, None, 64, 0, 1, 0, None, 0, _lib.VMF_F32, sp)
         assert rc == 0
     ms = timeit(f5, reps=10, warm=10)

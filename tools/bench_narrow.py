@@ -53,21 +53,21 @@ def main():
         z = torch.empty_like(mu)
 
         def f():
-            rc = lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(z), None, None, None, None, n, m,
+            rc = lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(z), None, None, None, None, None, n, m,
                                      None, None, 0, None, 64, 0, 1, 0, None, 0, _lib.dtype_code(mu), sp)
             assert rc == 0, lib.vmf_last_error_string()
         ms = timeit(f)
         # mean number of proposals per row on a sample of the rows
         ns = min(n, 1 << 20)
         acc = torch.empty(ns, device=DEV, dtype=torch.int32)
-        rc = lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(z), None, None, _lib.ptr(acc), None, ns, m,
+        rc = lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(z), None, None, _lib.ptr(acc), None, None, ns, m,
                                  None, None, 0, None, 64, 0, 1, 0, None, 0, _lib.dtype_code(mu), sp)
         assert rc == 0
         torch.cuda.synchronize()
         mean_prop = float(acc.float().mean()) + 1.0
         # backward: reads mu, grad_z, kappa, w, 1 - w; writes dmu, dkappa (noise regenerated)
         w, omw = torch.empty(n, device=DEV, dtype=dt), torch.empty(n, device=DEV, dtype=dt)
-        rc = lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(z), _lib.ptr(w), _lib.ptr(omw), None, None, n, m,
+        rc = lib.vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(z), _lib.ptr(w), _lib.ptr(omw), None, None, None, n, m,
                                  None, None, 0, None, 64, 0, 1, 0, None, 0, _lib.dtype_code(mu), sp)
         assert rc == 0
         gz = torch.randn_like(mu)
@@ -75,7 +75,7 @@ def main():
 
         def fb():
             rc = lib.vmf_rsample_bwd(_lib.ptr(mu), m, _lib.ptr(kap), 1, _lib.ptr(w), _lib.ptr(omw), _lib.ptr(gz), None,
-                                     _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 1, 0, None, 0, _lib.dtype_code(mu), sp)
+                                     None, _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 1, 0, None, 0, _lib.dtype_code(mu), sp)
             assert rc == 0, lib.vmf_last_error_string()
         msb = timeit(fb)
         print(f"| {m} | 2^{lg} | {ms:.3f} | {n * (2 * m + 1) * es / ms / 1e6:.0f} | {n / ms / 1e6:.2f} | {mean_prop:.3f} "
