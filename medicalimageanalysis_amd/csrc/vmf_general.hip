@@ -174,6 +174,7 @@ struct FwdParams {
   int mu_stride, kappa_stride, m, max_prop;
   int normalize;  // mu rows are raw: the sample is drawn around mu / ||mu||
   int softplus;   // kappa holds raw head outputs: the tile prologue turns them into kappa = softplus(raw) + 1
+  int dense16;    // one-lane-per-row kernel: mu rows are dense and mu / z 16-byte aligned (flat 128-bit tile moves)
   PhiloxArg ka;
   float lc_v, lc_lg, lc_c0;  // fp32 fused log_prob: m/2 - 1, lgamma(m/2), (m/2) log 2 pi
 };
@@ -507,6 +508,216 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
   }
 }
 
+// ---- narrow rows whose width is not a multiple of four (m = 3, 5, 6, 7, 9, 10, 11, 13, 14, 15; fp32, counter noise) -----
+// The lane-group mapping above gives such rows scalar, guarded element accesses and leaves lanes idle (m = 10: four
+// lanes per row, ten of their sixteen slots used).  Here ONE lane owns a row.  A wave's tile of 128 rows is 128 m
+// contiguous floats of mu: it moves between HBM and the wave as a flat array, 16 bytes per lane and access, fully
+// coalesced, and is parked in a wave-private LDS slab; a lane then reads its row from the slab (row stride m words:
+// conflict-free 32-bit reads for odd m, 64-bit reads for m = 2 mod 4), keeps the whole row in registers -- no
+// cross-lane sums at all -- writes z back over it, and the slab leaves as a flat array again.  The mu loads are issued
+// before the rejection phase and land while it runs.  Same counters, same noise, same arithmetic as the kernel above.
+// rows per wave: the rejection phase ends in a tail whose cost is per tile, so the narrowest rows take larger tiles (as in
+// the kernel above); the slab stays near 5-8 KiB per wave
+#ifndef VMF_RL_TILE_WIDE
+#define VMF_RL_TILE_WIDE 128
+#endif
+constexpr int rl_tile(int m) { return m <= 4 ? 384 : (m <= 7 ? 256 : VMF_RL_TILE_WIDE); }
+template <int M>
+__global__ __launch_bounds__(WAVES * 64) void vmf_rsample_rowlane_kernel(FwdParams<float> p) {
+  using T = float;
+  constexpr int RL_TILE = rl_tile(M);
+  constexpr int UNITS = RL_TILE * M / 4;  // 16-byte units of a full tile
+  constexpr int UPL = (UNITS + 63) / 64;  // per lane
+  constexpr int CHUNKS = (M + 3) / 4;
+  __shared__ T s_wc[WAVES][2][RL_TILE];
+  __shared__ float s_lc[WAVES][RL_TILE], s_kp[WAVES][RL_TILE];
+  __shared__ __align__(16) T s_rows[WAVES][RL_TILE * M];
+  const PhiloxKey key = philox_resolve(p.ka);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* const somw = s_wc[wave][0];
+  T* const sw = s_wc[wave][1];
+  float* const slc = s_lc[wave];
+  float* const skp = s_kp[wave];
+  T* const srow = s_rows[wave];
+  const int64_t tile0 = ((int64_t)blockIdx.x * WAVES + wave) * RL_TILE;  // wave-uniform
+  const int64_t left = p.n - tile0;
+  if (left <= 0) return;  // the kernel has no workgroup barrier
+  const int ntile = left < RL_TILE ? (int)left : RL_TILE;
+  // flat 128-bit moves for full tiles of dense, aligned rows; any other layout (views that start mid-allocation, one
+  // shared mean, padded rows) is gathered element by element -- same arithmetic, same bits
+  const bool full = p.dense16 && ntile == RL_TILE;
+  const T* const kap_t = p.kappa + tile0 * p.kappa_stride;
+  const uint64_t grow0 = p.row0 + (uint64_t)tile0;
+  const T* const mu_t = p.mu + tile0 * p.mu_stride;
+  T* const z_t = p.z + tile0 * M;
+  // the tile's mu, in flight during phase 1
+  u32x4 stage[UPL];
+  if (full) {
+#pragma unroll
+    for (int s = 0; s < UPL; ++s) {
+      const int q = lane + 64 * s;
+      if (UNITS % 64 == 0 || q < UNITS) stage[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(mu_t) + q);
+    }
+  }
+  // ---- phase 1: rejection sampler, one row per lane with ballot refill (as in vmf_rsample_fwd_kernel) ----
+  const bool sp = p.softplus != 0;
+  const bool lp = p.logp != nullptr;
+  for (int i = lane; i < ntile; i += 64) {
+    T sig_;
+    const T kap = kappa_of<T>(kap_t[i * p.kappa_stride], sp, &sig_);
+    if (p.kappa_out) p.kappa_out[tile0 + i] = kap;
+    if (lp) {
+      skp[i] = kap;
+      slc[i] = vmf_log_norm_f32v(p.lc_v, p.lc_lg, p.lc_c0, kap);
+    }
+    somw[i] = wood_b<T>(kap, M);
+  }
+  wave_lds_sync();
+  {
+    int my = lane, next = 64, k = 0;
+    bool active = my < ntile;
+    T b = active ? somw[my] : (T)0;
+    while (__ballot(active) != 0ull) {
+      bool acc = false;
+      if (active) {
+        T w, omw, c2;
+        const U4 r = philox4x32_10(grow0 + (uint64_t)my, (uint32_t)k, key);
+        acc = wood_try_counter<T>(b, M, u01<T>(r.x), u01<T>(r.y), u01<T>(r.z), &w, &omw, &c2);
+        if (k + 1 >= p.max_prop) acc = true;  // the last proposal allowed is taken regardless
+        if (acc) {
+          sw[my] = w;
+          somw[my] = c2;
+          if (p.w_out) p.w_out[tile0 + my] = w;
+          if (p.omw_out) p.omw_out[tile0 + my] = omw;
+          if (p.accept_idx) p.accept_idx[tile0 + my] = k;
+        }
+        ++k;
+      }
+      const unsigned long long accm = __ballot(acc);
+      if (acc) {
+        my = next + __popcll(accm & ((1ull << lane) - 1ull));
+        k = 0;
+        active = my < ntile;
+        if (active) b = somw[my];
+      }
+      next += __popcll(accm);
+    }
+  }
+  // ---- park the tile's mu in the slab ----
+  if (full) {
+#pragma unroll
+    for (int s = 0; s < UPL; ++s) {
+      const int q = lane + 64 * s;
+      if (UNITS % 64 == 0 || q < UNITS) reinterpret_cast<u32x4*>(srow)[q] = stage[s];
+    }
+  } else {
+    for (int e = lane; e < ntile * M; e += 64) srow[e] = mu_t[(e / M) * p.mu_stride + e % M];
+  }
+  wave_lds_sync();
+  // ---- phase 2: one row per lane ----
+#pragma unroll
+  for (int sub = 0; sub < RL_TILE / 64; ++sub) {
+    const int r = sub * 64 + lane;
+    if (r < ntile) {
+      T mu[M], g[M];
+      if (M % 2 == 0) {
+#pragma unroll
+        for (int e = 0; e < M; e += 2) {
+          const f32x2 v = *reinterpret_cast<const f32x2*>(srow + r * M + e);
+          mu[e] = v.x; mu[e + 1] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < M; ++e) mu[e] = srow[r * M + e];
+      }
+      // normals of elements 4c .. 4c+3 from Philox(row, SLOT_GAUSS + c), element 0 carries none
+#pragma unroll
+      for (int c = 0; c < CHUNKS; ++c) {
+        const U4 rr = philox4x32_10(grow0 + (uint64_t)r, SLOT_GAUSS + (uint32_t)c, key);
+        T n0, n1;
+        box_muller<T>(u01<T>(rr.x), u01<T>(rr.y), &n0, &n1);
+        if (4 * c < M) g[4 * c] = n0;
+        if (4 * c + 1 < M) g[4 * c + 1] = n1;
+        if (4 * c + 2 < M) {
+          box_muller<T>(u01<T>(rr.z), u01<T>(rr.w), &n0, &n1);
+          g[4 * c + 2] = n0;
+          if (4 * c + 3 < M) g[4 * c + 3] = n1;
+        }
+      }
+      g[0] = (T)0;
+      T gg = 0, tail = 0, gm = 0;
+#pragma unroll
+      for (int e = 1; e < M; ++e) {
+        gg += g[e] * g[e];
+        tail += mu[e] * mu[e];
+        gm += g[e] * mu[e];
+      }
+      T mu0 = mu[0];
+      const T inv = p.normalize ? F<T>::rsqrt(tail + mu0 * mu0) : (T)1;
+      mu0 *= inv;
+      gm *= inv;
+      const T d0 = (T)1 - mu0;
+      tail *= inv * inv;                // |mu|^2 without its first element
+      const T dd = d0 * d0 + tail;      // |e1 - mu|^2
+      const T w = sw[r];
+      T c2 = somw[r];
+      c2 = c2 < (T)1e-10 ? (T)1e-10 : c2;
+      const T f = F<T>::sqrt(c2) * F<T>::rsqrt(gg);
+      const T zd = w * d0 - f * gm;
+      const T coef = dd > (T)1e-30 ? (T)2 * zd * F<T>::rcp(dd) : (T)0;
+      const T coef_mu = coef * inv;
+      T z[M];
+      z[0] = w - coef * d0;
+#pragma unroll
+      for (int e = 1; e < M; ++e) z[e] = f * g[e] + coef_mu * mu[e];
+      if (M % 2 == 0) {
+#pragma unroll
+        for (int e = 0; e < M; e += 2) {
+          f32x2 v;
+          v.x = z[e]; v.y = z[e + 1];
+          *reinterpret_cast<f32x2*>(srow + r * M + e) = v;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < M; ++e) srow[r * M + e] = z[e];
+      }
+      if (lp) {  // <mu, z> through the two small quantities, as in the kernel above
+        const T mz = w * mu0 + f * gm - coef * (mu0 * d0 - tail);
+        slc[r] += skp[r] * mz;
+      }
+    }
+  }
+  wave_lds_sync();
+  if (full) {
+#pragma unroll
+    for (int s = 0; s < UPL; ++s) {
+      const int q = lane + 64 * s;
+      if (UNITS % 64 == 0 || q < UNITS) {
+        f32x4 v;
+        const u32x4 raw = reinterpret_cast<const u32x4*>(srow)[q];
+        __builtin_memcpy(&v, &raw, 16);
+        store_nt(v, z_t + 4 * q);
+      }
+    }
+  } else {
+    for (int e = lane; e < ntile * M; e += 64) z_t[e] = srow[e];
+  }
+  if (lp)
+    for (int i = lane; i < ntile; i += 64) p.logp[tile0 + i] = slc[i];
+}
+
+static bool rowlane_ok(int m) { return m >= 3 && m <= 15 && m % 4 != 0; }
+static void launch_rowlane(const FwdParams<float>& p, hipStream_t s) {
+  const int64_t tiles = (p.n + rl_tile(p.m) - 1) / rl_tile(p.m);
+  const dim3 grid((unsigned)((tiles + WAVES - 1) / WAVES)), block(WAVES * 64);
+  switch (p.m) {
+#define VMF_RL(MM) case MM: hipLaunchKernelGGL((vmf_rsample_rowlane_kernel<MM>), grid, block, 0, s, p); break
+    VMF_RL(3); VMF_RL(5); VMF_RL(6); VMF_RL(7); VMF_RL(9); VMF_RL(10); VMF_RL(11); VMF_RL(13); VMF_RL(14); VMF_RL(15);
+#undef VMF_RL
+    default: break;
+  }
+}
+
 // Backward: one pass over (grad_z, mu) rows; normals regenerated from the counters unless given.
 template <typename T, int LPR, int P, bool VEC>
 __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T> p) {
@@ -720,6 +931,15 @@ static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
                        kappa_stride, (T*)logp_out, n, make_vmf_dim(m), p.softplus);
   const bool pair_ok = m == 2 && !prop_e && !gauss && mu_stride % 2 == 0 && ((uintptr_t)mu % (2 * sizeof(T))) == 0 &&
                        ((uintptr_t)z % (2 * sizeof(T))) == 0;
+  if constexpr (sizeof(T) == 4) {
+    // narrow rows of a width that is not a multiple of four, counter noise: one lane per row whatever the layout, so that
+    // a draw does not depend on where a shard's rows start
+    if (rowlane_ok(m) && !prop_e) {
+      p.dense16 = mu_stride == m && aligned16(mu) && aligned16(z);
+      launch_rowlane(p, s);
+      return VMF_OK;
+    }
+  }
   if (pair_ok) {
     const int64_t nt = (n + VMF_TILE_ROWS_CIRCLE - 1) / VMF_TILE_ROWS_CIRCLE;
     hipLaunchKernelGGL((vmf_rsample_fwd_kernel<T, 1, 1, 3>), dim3((unsigned)((nt + WAVES - 1) / WAVES)), dim3(WAVES * 64), 0,

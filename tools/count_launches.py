@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Device kernel launches per train step (forward + ELBO + backward + Adam), with the encoder heads folded into the
+sampler kernels (model.forward) and without (encode -> reparemetrize -> decode, the sequence the reference writes),
+counted with torch.profiler.  Run on the GPU box:  python tools/count_launches.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
+from medicalimageanalysis_amd.model.hyperspherical_vae import HypersphericalVAE  # noqa: E402
+from medicalimageanalysis_amd.model.spherical_vae import SphericalVAE  # noqa: E402
+
+DEV = torch.device("cuda:0")
+STEPS = 10
+
+
+def count(model, fold):
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+    x = torch.rand(128, 784, device=DEV)
+
+    def step():
+        if fold:
+            z, x_mu, params = model(x)
+        else:
+            params = model.encode(x)
+            z = model.reparemetrize(params)
+            x_mu = model.decode(z)
+        loss = model._elbo(x, x_mu, params)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        for _ in range(STEPS):
+            step()
+        torch.cuda.synchronize()
+    kernels = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and "Memcpy" not in e.name
+               and "Memset" not in e.name]
+    ours = [e for e in kernels if "vmf" in e.name or "kl_" in e.name or "elbo" in e.name]
+    return len(kernels) / STEPS, len(ours) / STEPS
+
+
+def main():
+    torch.distributions.Distribution.set_default_validate_args(False)
+    base = dict(extrinsic_dim=784, sftbeta=1.0, encoder_width=128, encoder_depth=4, decoder_width=128, decoder_depth=4,
+                dropout_p=0.1, device="cuda", gamma=1.0, beta=0.01)
+    print("| model (batch 128, 28x28) | heads | kernel launches per step | of them libvmf_hip kernels |")
+    print("|---|---|---|---|")
+    for name, cls, latent in (("SphericalVAE, latent S^2 (z is (128,128,3))", SphericalVAE, 3),
+                              ("HypersphericalVAE, latent S^9", HypersphericalVAE, 10)):
+        for fold in (False, True):
+            torch.manual_seed(0)
+            model = cls(dict(base, latent_dim=latent))
+            total, ours = count(model, fold)
+            print(f"| {name} | {'folded into the sampler' if fold else 'torch ops (encode / reparemetrize)'} | {total:.1f} | "
+                  f"{ours:.1f} |", flush=True)
+
+
+if __name__ == "__main__":
+    main()
