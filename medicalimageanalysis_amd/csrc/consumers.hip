@@ -64,8 +64,7 @@ __global__ __launch_bounds__(256) void elbo_fwd_kernel(const T* __restrict__ x, 
     }
   }
   for (int64_t i = tid; i < n_kappa; i += nthreads) {
-    T g;
-    acc_kl += (double)kl_eval<T, BESSEL>(kappa[i], variant, kb, &g);
+    acc_kl += (double)kl_eval_value<T, BESSEL>(kappa[i], variant, kb);
   }
   double t0 = block_sum_double(acc_rec, red);
   __syncthreads();

@@ -107,29 +107,53 @@ extern "C" int vmf_bessel_ratio_fwd(double v, const void* z, void* out, int64_t 
 // model/spherical_vae.py:153-182 with one pass; the `.mean()` of :134 is the fused two-stage sum.
 // VEC = 4: 128-bit loads / stores of four consecutive elements per lane (fp32, 16-byte aligned); the n % 4 tail is
 // taken by the first lanes with scalar accesses.
-template <typename T, int VEC, bool BESSEL>
-__global__ __launch_bounds__(256) void kl_fwd_kernel(const T* __restrict__ kappa, T* __restrict__ out,
-                                                     double* __restrict__ partial, int64_t n, int variant,
-                                                     KlBessel kb) {
-  __shared__ double red[4];
+// Each lane keeps KL_UNROLL 128-bit loads in flight (the element loop is a dependent chain otherwise: one 1 KiB
+// request per wave at a time leaves HBM idle).  The <= 1024 block partials of the workspace cap the grid at four
+// 256-thread blocks per CU, which must all be resident at once (85 VGPRs: five waves per SIMD fit, four are needed);
+// 512-thread blocks ran the grid in two rounds.
+#ifndef VMF_KL_UNROLL
+#define VMF_KL_UNROLL 4
+#endif
+constexpr int KL_UNROLL = VMF_KL_UNROLL;
+constexpr int KL_BLOCK = 256;
+// VARIANT is a template argument: with the variant a run-time switch, every one of the 16 inlined per-element evaluations
+// of a trip carried all six forms (25 000 instructions in one kernel), and the kernels ran out of the instruction cache
+// rather than out of HBM.
+template <typename T, int VEC, bool BESSEL, int VARIANT>
+__global__ __launch_bounds__(KL_BLOCK) void kl_fwd_kernel(const T* __restrict__ kappa, T* __restrict__ out,
+                                                          double* __restrict__ partial, int64_t n, KlBessel kb) {
+  constexpr int variant = VARIANT;
+  __shared__ double red[KL_BLOCK / 64];
   double acc = 0;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t nvec = VEC == 4 ? n / 4 : 0;
-  for (int64_t i = tid; i < nvec; i += stride) {
-    const Vec4<T> k4 = *reinterpret_cast<const Vec4<T>*>(kappa + 4 * i);
-    Vec4<T> o4;
-    T g;
-    o4.v[0] = kl_eval<T, BESSEL>(k4.v[0], variant, kb, &g);
-    o4.v[1] = kl_eval<T, BESSEL>(k4.v[1], variant, kb, &g);
-    o4.v[2] = kl_eval<T, BESSEL>(k4.v[2], variant, kb, &g);
-    o4.v[3] = kl_eval<T, BESSEL>(k4.v[3], variant, kb, &g);
-    if (out) *reinterpret_cast<Vec4<T>*>(out + 4 * i) = o4;
-    acc += ((double)o4.v[0] + (double)o4.v[1]) + ((double)o4.v[2] + (double)o4.v[3]);
+  // a block takes KL_UNROLL consecutive 4 KiB pieces per trip, so that the loads a wave has in flight are neighbours
+  // (loads one grid stride -- a power of two -- apart land on the same HBM channels: 8 such streams ran at half the rate)
+  const int64_t chunk = (int64_t)blockDim.x * KL_UNROLL;
+  for (int64_t base = (int64_t)blockIdx.x * chunk; base < nvec; base += (int64_t)gridDim.x * chunk) {
+    Vec4<T> k4[KL_UNROLL];
+#pragma unroll
+    for (int u = 0; u < KL_UNROLL; ++u) {
+      const int64_t i = base + u * blockDim.x + threadIdx.x;
+      if (i < nvec) k4[u] = *reinterpret_cast<const Vec4<T>*>(kappa + 4 * i);
+    }
+#pragma unroll
+    for (int u = 0; u < KL_UNROLL; ++u) {
+      const int64_t i = base + u * blockDim.x + threadIdx.x;
+      if (i < nvec) {
+        Vec4<T> o4;
+        o4.v[0] = kl_eval_value<T, BESSEL>(k4[u].v[0], variant, kb);
+        o4.v[1] = kl_eval_value<T, BESSEL>(k4[u].v[1], variant, kb);
+        o4.v[2] = kl_eval_value<T, BESSEL>(k4[u].v[2], variant, kb);
+        o4.v[3] = kl_eval_value<T, BESSEL>(k4[u].v[3], variant, kb);
+        if (out) *reinterpret_cast<Vec4<T>*>(out + 4 * i) = o4;
+        acc += ((double)o4.v[0] + (double)o4.v[1]) + ((double)o4.v[2] + (double)o4.v[3]);
+      }
+    }
   }
   for (int64_t i = 4 * nvec + tid; i < n; i += stride) {
-    T g;
-    T kl = kl_eval<T, BESSEL>(kappa[i], variant, kb, &g);
+    T kl = kl_eval_value<T, BESSEL>(kappa[i], variant, kb);
     if (out) out[i] = kl;
     acc += (double)kl;
   }
@@ -148,10 +172,11 @@ __global__ __launch_bounds__(256) void kl_final_kernel(const double* __restrict_
   if (threadIdx.x == 0) *sum_out = alpha * t;
 }
 
-template <typename T, int VEC, bool BESSEL>
+template <typename T, int VEC, bool BESSEL, int VARIANT>
 __global__ __launch_bounds__(256) void kl_bwd_kernel(const T* __restrict__ kappa, const T* __restrict__ gout,
                                                      int64_t gstride, T gscale, T* __restrict__ dkappa, int64_t n,
-                                                     int variant, KlBessel kb) {
+                                                     KlBessel kb) {
+  constexpr int variant = VARIANT;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t nvec = VEC == 4 ? n / 4 : 0;
@@ -186,18 +211,27 @@ static int kl_fwd_launch(const char* who, const void* kappa, void* out, double* 
   VMF_REQUIRE(dtype == VMF_F32 || dtype == VMF_F64, VMF_ERR_DTYPE, "dtype %d", dtype);
   VMF_REQUIRE(n == 0 || kappa, VMF_ERR_BAD_ARG, "%s: null kappa", who);
   KlBessel kb = make_kl_bessel();
-  int grid = vmf_grid_for(dtype == VMF_F32 ? (n + 3) / 4 : n, 256, VMF_KL_WORKSPACE_DOUBLES);
+  int grid = vmf_grid_for(dtype == VMF_F32 ? (n + 3) / 4 : n, KL_BLOCK, VMF_KL_WORKSPACE_DOUBLES);
   if (n > 0) {
-    if (dtype == VMF_F32 && ew_aligned16(kappa) && ew_aligned16(out)) {
-      // fp32: every variant has a single-precision form, so this instantiation leaves the double-precision Bessel
-      // code out (46 instead of 149 VGPRs)
-      hipLaunchKernelGGL((kl_fwd_kernel<float, 4, false>), dim3(grid), dim3(256), 0, stream, (const float*)kappa,
-                         (float*)out, sum_out ? workspace : nullptr, n, variant, kb);
-    } else {
-      VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((kl_fwd_kernel<T, 1, true>), dim3(grid), dim3(256), 0, stream,
-                                                   (const T*)kappa, (T*)out, sum_out ? workspace : nullptr, n,
-                                                   variant, kb));
+#define VMF_KL_FWD(V)                                                                                                  \
+  case V:                                                                                                              \
+    if (dtype == VMF_F32 && ew_aligned16(kappa) && ew_aligned16(out))                                                  \
+      hipLaunchKernelGGL((kl_fwd_kernel<float, 4, false, V>), dim3(grid), dim3(KL_BLOCK), 0, stream,                   \
+                         (const float*)kappa, (float*)out, sum_out ? workspace : nullptr, n, kb);                      \
+    else if (dtype == VMF_F32)                                                                                         \
+      hipLaunchKernelGGL((kl_fwd_kernel<float, 1, true, V>), dim3(grid), dim3(KL_BLOCK), 0, stream,                    \
+                         (const float*)kappa, (float*)out, sum_out ? workspace : nullptr, n, kb);                      \
+    else                                                                                                               \
+      hipLaunchKernelGGL((kl_fwd_kernel<double, 1, true, V>), dim3(grid), dim3(KL_BLOCK), 0, stream,                   \
+                         (const double*)kappa, (double*)out, sum_out ? workspace : nullptr, n, kb);                    \
+    break
+    // fp32 with 128-bit accesses: every variant has a single-precision form, so that instantiation leaves the
+    // double-precision Bessel code out (46 instead of 149 VGPRs)
+    switch (variant) {
+      VMF_KL_FWD(0); VMF_KL_FWD(1); VMF_KL_FWD(2); VMF_KL_FWD(3); VMF_KL_FWD(4); VMF_KL_FWD(5);
+      default: break;
     }
+#undef VMF_KL_FWD
     int rc = vmf_check_launch(who);
     if (rc) return rc;
   }
@@ -271,15 +305,26 @@ extern "C" int vmf_kl_bwd(const void* kappa, const void* gout, int64_t gout_stri
   VMF_REQUIRE(kappa && gout && dkappa, VMF_ERR_BAD_ARG, "vmf_kl_bwd: null pointer");
   KlBessel kb = make_kl_bessel();
   int grid = vmf_grid_for(n, 256);
-  if (dtype == VMF_F32 && ew_aligned16(kappa) && ew_aligned16(dkappa) && (gout_stride == 0 || ew_aligned16(gout))) {
-    hipLaunchKernelGGL((kl_bwd_kernel<float, 4, false>), dim3(vmf_grid_for((n + 3) / 4, 256)), dim3(256), 0,
-                       (hipStream_t)stream, (const float*)kappa, (const float*)gout, gout_stride, (float)gscale,
-                       (float*)dkappa, n, variant, kb);
-  } else {
-    VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((kl_bwd_kernel<T, 1, true>), dim3(grid), dim3(256), 0,
-                                                 (hipStream_t)stream, (const T*)kappa, (const T*)gout, gout_stride,
-                                                 (T)gscale, (T*)dkappa, n, variant, kb));
+  const bool vec = dtype == VMF_F32 && ew_aligned16(kappa) && ew_aligned16(dkappa) && (gout_stride == 0 || ew_aligned16(gout));
+  VMF_REQUIRE(dtype == VMF_F32 || dtype == VMF_F64, VMF_ERR_DTYPE, "dtype %d is not VMF_F32/VMF_F64", dtype);
+#define VMF_KL_BWD(V)                                                                                                   \
+  case V:                                                                                                               \
+    if (vec)                                                                                                            \
+      hipLaunchKernelGGL((kl_bwd_kernel<float, 4, false, V>), dim3(vmf_grid_for((n + 3) / 4, 256)), dim3(256), 0,       \
+                         (hipStream_t)stream, (const float*)kappa, (const float*)gout, gout_stride, (float)gscale,      \
+                         (float*)dkappa, n, kb);                                                                        \
+    else if (dtype == VMF_F32)                                                                                          \
+      hipLaunchKernelGGL((kl_bwd_kernel<float, 1, true, V>), dim3(grid), dim3(256), 0, (hipStream_t)stream,             \
+                         (const float*)kappa, (const float*)gout, gout_stride, (float)gscale, (float*)dkappa, n, kb);   \
+    else                                                                                                                \
+      hipLaunchKernelGGL((kl_bwd_kernel<double, 1, true, V>), dim3(grid), dim3(256), 0, (hipStream_t)stream,            \
+                         (const double*)kappa, (const double*)gout, gout_stride, gscale, (double*)dkappa, n, kb);       \
+    break
+  switch (variant) {
+    VMF_KL_BWD(0); VMF_KL_BWD(1); VMF_KL_BWD(2); VMF_KL_BWD(3); VMF_KL_BWD(4); VMF_KL_BWD(5);
+    default: break;
   }
+#undef VMF_KL_BWD
   return vmf_check_launch("vmf_kl_bwd");
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include "bessel_dev.h"
 #include "common.h"
+#include "kl_m2_coeffs.h"
 
 // MP is the math policy of the call: M<T> (accurate library functions, IEEE division) or, for fp32 kernels, MFast
 // (hardware log2 / exp2 / sqrt / reciprocal).
@@ -261,7 +262,7 @@ VMF_HD float cheb_sum_f32(const float (&c)[n], float t) {
 // q = (sinh k + eps) / k - 1, so nothing cancels (the textbook order loses all digits of the O(k^2) result to
 // log k - log sinh k and 1/k - k / sinh^2 k).  The derivative uses cosh^2 - sinh^2 = 1:
 // d/dk = 1/k + k (eps sinh k - 1) / (sinh k + eps)^2.
-VMF_HD void kl_m3_eps_fast(float k, float eps, float* kl, float* g) {
+VMF_HD void kl_m3_eps_fast(float k, float eps, float* kl, float* g, bool finite_beyond = false) {
   if (k < 1.0f) {
     const float k2 = k * k;
     const float p = k2 * (1.0f / 6.0f + k2 * (1.0f / 120.0f + k2 * (1.0f / 5040.0f + k2 * (1.0f / 362880.0f))));
@@ -274,6 +275,21 @@ VMF_HD void kl_m3_eps_fast(float k, float eps, float* kl, float* g) {
     *kl = (c1 - q) * ropq - l1p;
     const float sh = k * (1.0f + p);
     *g = q * (2.0f + q) * (ropq * ropq * rk) + eps * sh * ropq * ropq * rk;
+    return;
+  }
+  // (finite_beyond: the caller's form has no overflow to reproduce -- e^-k underflows to 0 and leaves log k + ln 2 - 1)
+  if (k <= 85.0f || finite_beyond) {
+    // 1 <= k <= 85: everything through em = e^-k (one exponential, nothing overflows, nothing cancels).  With
+    // D = 1 - e^-2k + 2 eps e^-k:  sinh k + eps = D e^k / 2,  cosh k / (sinh k + eps) = (1 + e^-2k) / D, so
+    //   kl = log k + (ln 2 - 1) - log D + 2 k (e^-2k - eps e^-k) / D
+    //   d/dk = 1/k + k (2 eps e^-k (1 - e^-2k) - 4 e^-2k) / D^2
+    // -- the reference's expression term for term, eps included.  One straight-line path for every kappa an encoder
+    // produces (softplus + 1 >= 1), so a wave does not pay for several regions.
+    const float em = fast_exp2(-1.44269504088896340736f * k), e2 = em * em;
+    const float D = 1.0f - e2 + 2.0f * eps * em;
+    const float rD = fast_rcp(D);
+    *kl = fast_log(k) + (0.69314718055994530942f - 1.0f) - fast_log(D) + 2.0f * k * (e2 - eps * em) * rD;
+    *g = fast_rcp(k) + k * (2.0f * eps * em * (1.0f - e2) - 4.0f * e2) * (rD * rD);
     return;
   }
   float sh, C;
@@ -299,6 +315,12 @@ VMF_HD bool kl_value_fast(float kappa, int variant, float* kl_out, float* grad) 
       const float pass = (kappa >= eps) ? 1.0f : 0.0f;
       if (k < 1e-3f) {
         kl = 0.0f; g = 0.0f;
+      } else if (k >= 1.0f && k <= 1000.0f) {
+        // the mid form; beyond 20 the reference switches to log k - (k - ln 2) + k (1 + 2 e^-2k) - 1, which differs
+        // from it by O(e^-2k) < 1e-17: the same float.  (Beyond 1000 the reference's own fp32 result carries the
+        // rounding of k - k: its order of operations is kept there, below.)
+        kl_m3_eps_fast(k, eps, &kl, &g, true);
+        g *= pass;
       } else if (k > 20.0f) {
         const float e2 = fast_exp(-2.0f * k);
         const float coth = 1.0f + 2.0f * e2;
@@ -394,6 +416,26 @@ VMF_HD bool kl_value_fast(float kappa, int variant, float* kl_out, float* grad) 
   return true;
 }
 
+// KL(vM(kappa) || U(S^1)) = kappa I1/I0 - log I0, the VALUE alone (what the fused sums and the per-element forward
+// need), from polynomial fits of the function itself: one Horner chain of 11 / 17 / 13 terms per element instead of the
+// two Chebyshev series (20 + 29 or 8 + 11 terms at two instructions each) that the value-and-derivative form evaluates.
+template <int n>
+VMF_HD float horner_f32(const float (&c)[n], float t) {
+  float acc = c[n - 1];
+#pragma unroll
+  for (int k = n - 2; k >= 0; --k) acc = ::fmaf(acc, t, c[k]);
+  return acc;
+}
+VMF_HD float kl_m2_value_f32(float a) {  // a = |kappa|, finite
+  if (a <= 2.0f) {
+    const float y = 0.25f * a * a;
+    return y * horner_f32(KLM2_S, 2.0f * y - 1.0f);
+  }
+  if (a <= 8.0f) return horner_f32(KLM2_M, (a - 5.0f) * (1.0f / 3.0f));
+  const float ra = fast_rcp(a);
+  return 0.5f * fast_log(a) + KLM2_C0 + horner_f32(KLM2_L, 16.0f * ra - 1.0f);
+}
+
 // log C_2(k) = -log 2pi - log(I0(k) e^-k) - k for the circle, single precision, k > 0: the Chebyshev series of i0e
 // (about twenty fused multiply-adds on [0,8], eight beyond) instead of the general-order power series / Debye sum,
 // whose data-dependent trip count made the fused log_prob the larger half of the circle sampler's time.
@@ -426,6 +468,27 @@ VMF_HD float kl_eval<float, false>(float kappa, int variant, const KlBessel& kb,
   if (kl_value_fast(kappa, variant, &kl, grad)) return kl;
   return kl_value<float, false>(kappa, variant, kb, grad);
 }
+
+// value alone (forward kernels): the compiler drops the derivative of the forms above by itself; the two S^1 variants
+// take their own value-only fits.  VMF_KL_S1_I0I1 keeps the reference's overflow behaviour (NaN once I0 leaves the
+// float range, kappa > ~91.9) through the value-and-derivative form beyond 85.
+template <typename T, bool BESSEL>
+VMF_HD T kl_eval_value(T kappa, int variant, const KlBessel& kb) {
+  T g;
+  return kl_eval<T, BESSEL>(kappa, variant, kb, &g);
+}
+#define VMF_KL_VALUE_F32(BESSEL)                                                                              \
+  template <>                                                                                                 \
+  VMF_HD float kl_eval_value<float, BESSEL>(float kappa, int variant, const KlBessel& kb) {                   \
+    const float a = ::fabsf(kappa);                                                                           \
+    if ((variant == VMF_KL_STABLE_M2 && a <= 3.0e38f) || (variant == VMF_KL_S1_I0I1 && a <= 85.0f))           \
+      return kl_m2_value_f32(a);                                                                              \
+    float g;                                                                                                  \
+    return kl_eval<float, BESSEL>(kappa, variant, kb, &g);                                                    \
+  }
+VMF_KL_VALUE_F32(true)
+VMF_KL_VALUE_F32(false)
+#undef VMF_KL_VALUE_F32
 
 // ---- general-m pieces ---------------------------------------------------------------------------
 template <typename T>

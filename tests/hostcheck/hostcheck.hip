@@ -70,6 +70,12 @@ int hc_kl_fast_f32(const float* k, float* out, float* dout, int64_t n, int varia
   for (int64_t i = 0; i < n; ++i) ok &= (int)kl_value_fast(k[i], variant, &out[i], &dout[i]);
   return ok;
 }
+// the value-only form of the fp32 forward kernels (for the S^1 variants: polynomial fits of the KL itself)
+void hc_kl_value_f32(const float* k, float* out, int64_t n, int variant) {
+  KlBessel kb = make_kl_bessel();
+  for (int64_t i = 0; i < n; ++i) out[i] = kl_eval_value<float, false>(k[i], variant, kb);
+}
+
 void hc_kl_f32(const float* k, float* out, float* dout, int64_t n, int variant) {
   KlBessel kb = make_kl_bessel();
   for (int64_t i = 0; i < n; ++i) out[i] = kl_value<float>(k[i], variant, kb, &dout[i]);

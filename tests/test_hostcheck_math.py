@@ -206,3 +206,31 @@ def test_device_wood_accept_index_bit_exact(hc, oracle):
         hc.hc_wood_f64(_p(kappa), _p(pe), _p(pu), _p(w), _p(idx), C.c_int64(n), m, K)
         np.testing.assert_array_equal(idx, idx_ref)
         np.testing.assert_allclose(w, w_ref, rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+def test_fp32_forward_value_only_forms_match_oracle(hc, oracle, variant):
+    """what the fp32 forward kernels evaluate per element (kl_eval_value): for the S^1 variants polynomial fits of
+    kappa I1/I0 - log I0 itself, for the m = 3 variants one e^-kappa form from kappa = 1 on; against the oracle in double
+    on a dense grid, and the reference's NaN behaviour beyond the overflow point"""
+    kk = np.exp(np.linspace(np.log(2e-3), np.log(85.0), 8001)).astype(np.float32)
+    out = np.empty_like(kk)
+    hc.hc_kl_value_f32(_p(kk), _p(out), C.c_int64(kk.size), variant)
+    r64, _, _ = oracle.vmf_kl(kk.astype(np.float64), variant)
+    np.testing.assert_allclose(out, r64, rtol=2e-5, atol=3e-6)
+    # (variant 0 keeps the reference's own order log k - (k - ln 2) + k coth k - 1 beyond 85, which loses digits to k in
+    #  fp32 as the reference's fp32 result does: 1e5 is left to the variants without that cancellation)
+    big = np.array([89.5, 95.0, 1e3, 1e4] + ([1e5] if variant else []), dtype=np.float32)
+    ob = np.empty_like(big)
+    hc.hc_kl_value_f32(_p(big), _p(ob), C.c_int64(big.size), variant)
+    if variant in (1, 2):
+        assert np.isnan(ob).all()
+    elif variant == 3:
+        assert np.isnan(ob[1:]).all()          # I0 leaves the float range beyond kappa ~ 91.9
+    else:
+        rb, _, _ = oracle.vmf_kl(big.astype(np.float64), variant)
+        np.testing.assert_allclose(ob, rb, rtol=2e-5)
+    if variant in (3, 5):                       # even in kappa
+        neg = np.empty_like(kk)
+        hc.hc_kl_value_f32(_p(-kk), _p(neg), C.c_int64(kk.size), variant)
+        np.testing.assert_array_equal(neg, out)
