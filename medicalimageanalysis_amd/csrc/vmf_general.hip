@@ -966,10 +966,13 @@ extern "C" int vmf_rsample_fwd(const void* mu, int64_t mu_stride, const void* ka
   const bool pre = prop_e || prop_u || gauss;
   if (pre) {
     VMF_REQUIRE(prop_e && prop_u && gauss, VMF_ERR_BAD_ARG, "pre-drawn mode needs prop_e, prop_u and gauss");
-    VMF_REQUIRE(n_prop >= 1, VMF_ERR_BAD_ARG, "n_prop=%d < 1", n_prop);
+    VMF_REQUIRE(n_prop >= 1 && n_prop <= 65536, VMF_ERR_BAD_ARG, "n_prop=%d outside [1, 65536]", n_prop);
   } else {
-    VMF_REQUIRE(max_prop >= 1, VMF_ERR_BAD_ARG, "max_prop=%d < 1", max_prop);
+    // proposal k draws from Philox slot k and the Gaussians from slots 0x10000 + chunk: more than 65536 proposals would
+    // reuse counters (and a NaN kappa, which never accepts, would spin its wave up to the cap)
+    VMF_REQUIRE(max_prop >= 1 && max_prop <= 65536, VMF_ERR_BAD_ARG, "max_prop=%d outside [1, 65536]", max_prop);
   }
+  VMF_REQUIRE(mu_stride <= 0x7fffffff, VMF_ERR_UNSUPPORTED, "mu_stride=%lld does not fit 32 bits", (long long)mu_stride);
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(mu && kappa && z, VMF_ERR_BAD_ARG, "vmf_rsample_fwd: null mu/kappa/z");
   int rc;

@@ -64,6 +64,24 @@ def log_ive(v, z):
     return _launch_unary("vmf_log_ive_fwd", v, z)
 
 
+class _BesselRatio(torch.autograd.Function):
+    """A(z) = I_v(z) / I_{v-1}(z) with dA/dz = 1 - (2v - 1) A / z - A^2"""
+
+    @staticmethod
+    def forward(ctx, v, z):
+        a = _launch_unary("vmf_bessel_ratio_fwd", v, z.detach())
+        ctx.save_for_backward(z.detach(), a)
+        ctx.v = float(v)
+        return a
+
+    @staticmethod
+    def backward(ctx, g):
+        z, a = ctx.saved_tensors
+        return None, g * (1 - (2 * ctx.v - 1) * a / z - a * a)
+
+
 def bessel_ratio(v, z):
-    """I_v(z) / I_{v-1}(z), v >= 1 (no reference counterpart)."""
+    """I_v(z) / I_{v-1}(z), v >= 1 (no reference counterpart); differentiable in z."""
+    if z.requires_grad:
+        return _BesselRatio.apply(v, z)
     return _launch_unary("vmf_bessel_ratio_fwd", v, z)

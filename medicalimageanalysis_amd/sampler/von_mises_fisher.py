@@ -371,16 +371,43 @@ class VonMisesFisher3DLogProb(VonMisesFisher3D):
         return _VMF3LogProbRef.apply(locb, scaleb, xb)
 
     def _log_normalization(self):
+        """log kappa - log 4 pi - log(sinh kappa + 1e-10) (:97-108), differentiable in kappa as in the reference"""
         loc = self._loc_raw.detach()
         bshape = torch.broadcast_shapes(loc.shape[:-1], self.scale.shape)
-        scaleb = self.scale.detach().to(loc.dtype).expand(bshape).contiguous()
-        dev = _lib.require_hip(scaleb)
-        lognorm = torch.empty(bshape, device=dev, dtype=loc.dtype)
+        scaleb = self.scale.to(loc.dtype).expand(bshape)
+        if scaleb.numel() == 0:
+            return loc.new_empty(bshape)
+        return _VMF3LogNormRef.apply(scaleb)
+
+
+class _VMF3LogNormRef(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scale):
+        dev = _lib.require_hip(scale)
+        sc = scale.detach().contiguous()
+        lognorm = torch.empty_like(sc)
         with torch.cuda.device(dev):
-            rc = _lib.lib().vmf3_log_prob_ref(None, _lib.ptr(scaleb), None, None, _lib.ptr(lognorm), scaleb.numel(),
-                                              _lib.dtype_code(scaleb), _lib.stream_ptr(dev))
+            rc = _lib.lib().vmf3_log_prob_ref(None, _lib.ptr(sc), None, None, _lib.ptr(lognorm), sc.numel(),
+                                              _lib.dtype_code(sc), _lib.stream_ptr(dev))
         _lib.check(rc, "vmf3_log_prob_ref")
+        ctx.save_for_backward(sc)
         return lognorm
+
+    @staticmethod
+    def backward(ctx, g):
+        # log_prob = kappa <l, x> - lognorm: with x = 0 the backward kernel's dscale is -g d lognorm / d kappa
+        (sc,) = ctx.saved_tensors
+        dev = sc.device
+        gl = (-g).to(sc.dtype).contiguous()
+        x = torch.zeros(sc.shape + (3,), device=dev, dtype=sc.dtype)
+        loc = torch.ones_like(x)
+        dscale = torch.empty_like(sc)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().vmf3_log_prob_ref_bwd(_lib.ptr(loc), _lib.ptr(sc), _lib.ptr(x), _lib.ptr(gl), None,
+                                                  _lib.ptr(dscale), None, sc.numel(), _lib.dtype_code(sc),
+                                                  _lib.stream_ptr(dev))
+        _lib.check(rc, "vmf3_log_prob_ref_bwd")
+        return dscale
 
 
 # ---- general m ---------------------------------------------------------------------------------------------
@@ -548,12 +575,20 @@ class VonMisesFisher(Distribution):
         return self._loc_unit
 
     def _kappa_rows(self):
+        """kappa per batch element.  scale must have the batch shape, the batch shape + (1,) (what a linear head with
+        one output gives), or be broadcastable to the batch shape without a trailing 1 that could be taken for either"""
         k = self.scale.to(self.dtype)
-        if k.dim() == self._loc_given.dim() and k.shape[-1] == 1:
+        bs = tuple(self.batch_shape)
+        if tuple(k.shape) == bs + (1,):
             k = k.squeeze(-1)
+        elif k.dim() == len(bs) + 1:
+            raise ValueError(f"VonMisesFisher: scale of shape {tuple(k.shape)} does not match batch shape {bs} "
+                             f"(expected {bs} or {bs + (1,)})")
         return k.expand(self.batch_shape).reshape(-1)
 
     def rsample(self, sample_shape=torch.Size(), return_log_prob=False):
+        """return_log_prob=True also returns log p(z), fused into the sampler kernel: a VALUE (detached) -- for a term
+        that must carry gradients (an entropy estimate in a loss) call log_prob(z), which is differentiable"""
         sample_shape = torch.Size(sample_shape)
         nb, S = _numel(self.batch_shape), _numel(sample_shape)
         n = nb * S
@@ -609,7 +644,7 @@ class VonMisesFisher(Distribution):
     @property
     def mean(self):
         from .ive import bessel_ratio
-        A = bessel_ratio(self.m / 2, self._kappa_rows().detach()).view(self.batch_shape)
+        A = bessel_ratio(self.m / 2, self._kappa_rows()).view(self.batch_shape)  # differentiable in kappa
         return self.loc * A.unsqueeze(-1)
 
     @property

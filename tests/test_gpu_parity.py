@@ -738,6 +738,14 @@ def test_general_rsample_philox_vs_oracle(oracle, tag, m, n):
     assert same.mean() >= (1.0 if tag == "f64" else 0.9995), same.mean()
     close(w[same], w_ref[same], tag, atol64=1e-11, atol32=2e-5)
     close(z[same], z_ref[same], tag, atol64=1e-9, atol32=1e-4)
+    # rows whose accept test flipped took a neighbouring proposal: still a valid draw -- unit norm, <z, mu> = the w the
+    # kernel reports, and a proposal index one step from the oracle's
+    other = ~same
+    if other.any():
+        at = 1e-9 if tag == "f64" else 2e-5
+        np.testing.assert_allclose(np.linalg.norm(z[other].astype(np.float64), axis=1), 1.0, atol=at)
+        np.testing.assert_allclose((z[other].astype(np.float64) * mu[other]).sum(1), w[other], atol=at)
+        assert (w[other] >= -1).all() and (w[other] <= 1).all() and (idx[other] >= 0).all() and (idx[other] < 64).all()
     # sharding: rows [a, b) computed alone with row0 + a reproduce the slice bit for bit
     a, b = n // 3, n // 3 + min(777, n // 2)
     z2 = torch.empty((b - a, m), device=DEV, dtype=TD[tag])
@@ -877,7 +885,10 @@ def test_general_rsample_full_size_properties():
     _lib.check(rc, "vmf_rsample_fwd")
     assert float((z.norm(dim=-1) - 1).abs().max()) < 1e-4
     assert float(((z * mu).sum(-1) - w).abs().max()) < 1e-4
-    assert int(idx.max()) < 63 and int(idx.min()) == 0
+    assert int(idx.min()) == 0
+    # the proposal cap (max_prop = 64) takes the last proposal unconditionally: it must never fire at this size
+    assert int((idx == 63).sum()) == 0, "forced acceptances"
+    assert int(idx.max()) < 40, int(idx.max())
     # E[w] ~ A_m(kappa) on a narrow kappa band
     band = (kappa > 90) & (kappa < 110)
     A = float(bessel_ratio(32.0, torch.tensor([100.0], device=DEV, dtype=torch.float64)))
@@ -910,6 +921,13 @@ def test_high_dim_regime_full_size_properties():
     band = (kappa > 900) & (kappa < 1100)
     A = float(bessel_ratio(256.0, torch.tensor([1000.0], device=DEV, dtype=torch.float64)))
     assert abs(float((z[band] * mu[band]).sum(-1).mean()) - A) < 5e-3
+    # no forced acceptance (the proposal cap of 64) anywhere in this regime either
+    idx = torch.empty(n, device=DEV, dtype=torch.int32)
+    rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(z), None, None, C.c_void_p(idx.data_ptr()),
+                                    None, None, n, m, None, None, 0, None, 64, 0, 11, 0, None, 0, _lib.VMF_F32,
+                                    _lib.stream_ptr(DEV))
+    _lib.check(rc, "vmf_rsample_fwd")
+    assert int((idx == 63).sum()) == 0 and int(idx.max()) < 40, int(idx.max())
 
 
 def test_product_of_circles_and_s1_sampler_large():
@@ -925,6 +943,14 @@ def test_product_of_circles_and_s1_sampler_large():
     kappa = torch.exp(torch.rand(n, device=DEV, generator=g) * np.log(1e3))
     z = VonMisesFisher(mu, kappa, validate_args=False).rsample().view(rows, circles, 2)
     assert float((z.norm(dim=-1) - 1).abs().max()) < 1e-5
+    idx = torch.empty(n, device=DEV, dtype=torch.int32)
+    zz2 = torch.empty_like(mu)
+    rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(mu), 2, _lib.ptr(kappa), 1, _lib.ptr(zz2), None, None, C.c_void_p(idx.data_ptr()),
+                                    None, None, n, 2, None, None, 0, None, 64, 0, 5, 0, None, 0, _lib.VMF_F32,
+                                    _lib.stream_ptr(DEV))
+    _lib.check(rc, "vmf_rsample_fwd")
+    assert int((idx == 63).sum()) == 0 and int(idx.max()) < 48, int(idx.max())   # the proposal cap never fires
+    del idx, zz2
     # angle offsets follow the von Mises law: check one narrow kappa band with a KS test
     band = ((kappa > 4.9) & (kappa < 5.1)).view(rows, circles)
     d = z[band].double()
@@ -1272,6 +1298,32 @@ def test_general_log_prob_entropy_kl(oracle, tag, m):
         A = oracle.bessel_ratio(m / 2, kappa)
         np.testing.assert_allclose(N(tk.grad), (mu * x).sum(1) - A, rtol=1e-8, atol=1e-9)
         np.testing.assert_allclose(N(tm.grad), kappa[:, None] * x, rtol=1e-12)
+
+
+def test_gradients_reach_kappa_through_lognorm_and_mean():
+    """CNN_experiment/von_mises_fisher.py:97-108 is differentiable in kappa, and so is the general-m mean A_m(kappa) mu"""
+    k = (torch.rand(50, device=DEV, dtype=torch.float64) * 30 + 0.5).requires_grad_()
+    loc = torch.randn(50, 3, device=DEV, dtype=torch.float64)
+    ln = VonMisesFisher3DLogProb(loc, k, validate_args=False)._log_normalization()
+    ln.sum().backward()
+    kk = k.detach().clone().requires_grad_()
+    ref = kk.log() - np.log(4 * np.pi) - torch.log(torch.sinh(kk) + 1e-10)
+    ref.sum().backward()
+    np.testing.assert_allclose(N(ln), N(ref), rtol=1e-12)
+    np.testing.assert_allclose(N(k.grad), N(kk.grad), rtol=1e-10)
+    m = 10
+    k2 = (torch.rand(40, device=DEV, dtype=torch.float64) * 50 + 1).requires_grad_()
+    mu = torch.nn.functional.normalize(torch.randn(40, m, device=DEV, dtype=torch.float64), dim=-1)
+    mean = VonMisesFisher(mu, k2, validate_args=False).mean
+    c = torch.randn_like(mean)
+    (mean * c).sum().backward()
+    h = 1e-6
+    up = VonMisesFisher(mu, k2.detach() + h, validate_args=False).mean
+    dn = VonMisesFisher(mu, k2.detach() - h, validate_args=False).mean
+    fd = ((up - dn) / (2 * h) * c).sum(-1)
+    np.testing.assert_allclose(N(k2.grad), N(fd), rtol=1e-6, atol=1e-9)
+    with pytest.raises(ValueError, match="does not match batch shape"):
+        VonMisesFisher(mu, torch.ones(40, 2, device=DEV, dtype=torch.float64), validate_args=False).rsample()
 
 
 def test_general_shared_parameters_and_shapes():
