@@ -107,11 +107,15 @@ struct U4 {
   uint32_t x, y, z, w;
 };
 
+// (VMF_PHILOX_ROUNDS exists for timing ablations only: every test pins the 10-round generator)
+#ifndef VMF_PHILOX_ROUNDS
+#define VMF_PHILOX_ROUNDS 10
+#endif
 __device__ __forceinline__ U4 philox4x32_10(uint64_t index, uint32_t slot, PhiloxKey key) {
   uint32_t c0 = (uint32_t)index, c1 = (uint32_t)(index >> 32), c2 = slot, c3 = key.c3;
   uint32_t k0 = key.k0, k1 = key.k1;
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < VMF_PHILOX_ROUNDS; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;

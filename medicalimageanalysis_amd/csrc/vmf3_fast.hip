@@ -220,14 +220,23 @@ int vmf3_bwd_rows(const V3Call& c, int64_t n) {
 constexpr int V3_OUTER_J = 256;            // loc rows per block: 768 flattened columns, 12 per lane
 constexpr int V3_OUTER_E = 3 * V3_OUTER_J;
 constexpr int V3_OUTER_MAX_RPW = 16;       // rows i per wave (4 waves per block)
+// smallest grid worth keeping when a larger tile is possible.  The backward wants large tiles (its column partials shrink
+// with the tile height: (4096, 4096, 3) ran 0.057 / 0.072 / 0.127 ms at 1024 / 2048 / 4096 blocks); the forward only
+// amortises a prologue and ran 0.0412 / 0.0402 / 0.0387 ms.
+#ifndef VMF3_OUTER_MIN_BLOCKS_FWD
+#define VMF3_OUTER_MIN_BLOCKS_FWD 4096
+#endif
+#ifndef VMF3_OUTER_MIN_BLOCKS_BWD
+#define VMF3_OUTER_MIN_BLOCKS_BWD 1024
+#endif
 
 // Rows per wave: large tiles amortise the block's prologue (256 direction rows + its w's: 2 % of the work at 16 rows per
 // wave) and shrink the backward's column partials; small problems take small tiles so that the grid still fills the chip.
-static int v3_outer_rpw(int64_t n_i, int64_t n_j) {
+static int v3_outer_rpw(int64_t n_i, int64_t n_j, int64_t min_blocks) {
   const int64_t ntj = (n_j + V3_OUTER_J - 1) / V3_OUTER_J;
   for (int rpw = V3_OUTER_MAX_RPW; rpw > 1; rpw >>= 1) {
     const int64_t nti = (n_i + 4 * rpw - 1) / (4 * rpw);
-    if (nti * ntj >= 1024) return rpw;
+    if (nti * ntj >= min_blocks) return rpw;
   }
   return 1;
 }
@@ -417,7 +426,9 @@ __global__ __launch_bounds__(256) void vmf3_outer_bwd_kernel(const T* __restrict
   }
 }
 
-// Backward, second launch: partials added in index order, then the chain rules of sampler/von_mises_fisher.py:58-63
+constexpr int V3_FIN_IDX = 32, V3_FIN_SUBS = 8;  // finish kernel: 256 threads = 32 indices x 8 lanes
+
+// Backward, second launch: partials added in a fixed order, then the chain rules of sampler/von_mises_fisher.py:58-63
 // (per i) and :30, :77-79 (per j).
 template <typename T, typename MP>
 __global__ __launch_bounds__(256) void vmf3_outer_bwd_finish_kernel(const T* __restrict__ loc,
@@ -428,27 +439,62 @@ __global__ __launch_bounds__(256) void vmf3_outer_bwd_finish_kernel(const T* __r
                                                                     const T* __restrict__ colp, T* __restrict__ dloc,
                                                                     T* __restrict__ dscale, int64_t n_i, int64_t n_j,
                                                                     int ntj, int64_t nti, int softplus, PhiloxArg ka) {
+  // 32 indices per block, eight lanes each: lane `sub` adds tiles sub, sub + 8, ... in rising order, the eight sums are
+  // then added in lane order -- the same bits every run.  One lane per index left this launch on sixteen compute units
+  // with a chain of dependent loads each.
+  __shared__ T sP[V3_FIN_SUBS][V3_FIN_IDX][8];
   const PhiloxKey key = philox_resolve(ka);
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int il = threadIdx.x & (V3_FIN_IDX - 1), sub = threadIdx.x / V3_FIN_IDX;
+  const int64_t idx = (int64_t)blockIdx.x * V3_FIN_IDX + il;
+  T acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // a, b | dl0, dv0, dl1, dv1, dl2, dv2
   if (idx < n_i) {
-    T a = 0, b = 0;
-    for (int t = 0; t < ntj; ++t) {
-      const Pair<T> pr = reinterpret_cast<const Pair<T>*>(rowp)[(int64_t)t * n_i + idx];
-      a += pr.a;
-      b += pr.b;
+    for (int t0 = sub; t0 < ntj; t0 += 4 * V3_FIN_SUBS) {
+      Pair<T> pr[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        if (t0 + x * V3_FIN_SUBS < ntj)
+          pr[x] = reinterpret_cast<const Pair<T>*>(rowp)[(int64_t)(t0 + x * V3_FIN_SUBS) * n_i + idx];
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        if (t0 + x * V3_FIN_SUBS < ntj) { acc[0] += pr[x].a; acc[1] += pr[x].b; }
     }
+  }
+  if (idx < n_j) {
+    for (int64_t t0 = sub; t0 < nti; t0 += 4 * V3_FIN_SUBS) {
+      Pair<T> pr[4][3];
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        if (t0 + x * V3_FIN_SUBS < nti) {
+          const Pair<T>* p = reinterpret_cast<const Pair<T>*>(colp) + ((t0 + x * V3_FIN_SUBS) * n_j + idx) * 3;
+          pr[x][0] = p[0]; pr[x][1] = p[1]; pr[x][2] = p[2];
+        }
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        if (t0 + x * V3_FIN_SUBS < nti) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { acc[2 + 2 * c] += pr[x][c].a; acc[3 + 2 * c] += pr[x][c].b; }
+        }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) sP[sub][il][c] = acc[c];
+  __syncthreads();
+  if (sub == 0 && idx < n_i) {  // wave 0 finishes the rows, wave 1 the columns
+    T a = 0, b = 0;
+#pragma unroll
+    for (int q = 0; q < V3_FIN_SUBS; ++q) { a += sP[q][il][0]; b += sP[q][il][1]; }
     T sig = (T)1;
     const T k = softplus ? v3_softplus_kappa<T, MP>(scale[idx], &sig) : scale[idx];
     T dk = v3_bwd_scale<T, MP>(k, v3_draw_u<T>(u, idx, key), a, b);
     if (gkappa) dk += gkappa[idx];
     dscale[idx] = dk * sig;
   }
-  if (idx < n_j) {
+  if (sub == 2 && idx < n_j) {
     T dl[3] = {0, 0, 0}, dv[3] = {0, 0, 0};
-    for (int64_t t = 0; t < nti; ++t) {
-      const T* p = colp + (t * n_j + idx) * 6;
-      dl[0] += p[0]; dv[0] += p[1]; dl[1] += p[2]; dv[1] += p[3]; dl[2] += p[4]; dv[2] += p[5];
-    }
+#pragma unroll
+    for (int q = 0; q < V3_FIN_SUBS; ++q)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { dl[c] += sP[q][il][2 + 2 * c]; dv[c] += sP[q][il][3 + 2 * c]; }
     const T r[3] = {loc[3 * idx], loc[3 * idx + 1], loc[3 * idx + 2]};
     T e[3], dr[3];
     v3_draw_eps<T>(eps, idx, key, e);
@@ -462,8 +508,9 @@ static bool outer_vec_ok(const void* p, int64_t n_j, int dtype) {
   return v3_aligned16(p) && row_bytes % 16 == 0;
 }
 
-static int outer_grid(int64_t n_i, int64_t n_j, int* ntj_out, int64_t* nti_out, int* rpw_out, const char* who) {
-  const int rpw = v3_outer_rpw(n_i, n_j);
+static int outer_grid(int64_t n_i, int64_t n_j, int64_t min_blocks, int* ntj_out, int64_t* nti_out, int* rpw_out,
+                      const char* who) {
+  const int rpw = v3_outer_rpw(n_i, n_j, min_blocks);
   const int64_t ntj = (n_j + V3_OUTER_J - 1) / V3_OUTER_J, nti = (n_i + 4 * rpw - 1) / (4 * rpw);
   VMF_REQUIRE(ntj < (1 << 24) && nti * ntj < 0x7fffffff, VMF_ERR_UNSUPPORTED, "%s: (%lld, %lld, 3) exceeds the grid", who,
               (long long)n_i, (long long)n_j);
@@ -486,7 +533,7 @@ static void launch_outer_fwd(const V3Call& c, int64_t n_i, int64_t n_j, int ntj,
 int vmf3_fwd_outer(const V3Call& c, int64_t n_i, int64_t n_j) {
   int ntj, rpw;
   int64_t nti;
-  int rc = outer_grid(n_i, n_j, &ntj, &nti, &rpw, "vmf3_rsample_fwd");
+  int rc = outer_grid(n_i, n_j, VMF3_OUTER_MIN_BLOCKS_FWD, &ntj, &nti, &rpw, "vmf3_rsample_fwd");
   if (rc) return rc;
   if (c.dtype == VMF_F32) launch_outer_fwd<float, MFast>(c, n_i, n_j, ntj, nti, rpw);
   else launch_outer_fwd<double, M<double>>(c, n_i, n_j, ntj, nti, rpw);
@@ -494,7 +541,7 @@ int vmf3_fwd_outer(const V3Call& c, int64_t n_i, int64_t n_j) {
 }
 
 int64_t vmf3_bwd_outer_workspace_bytes(int64_t n_i, int64_t n_j, int dtype) {
-  const int rpw = v3_outer_rpw(n_i, n_j);
+  const int rpw = v3_outer_rpw(n_i, n_j, VMF3_OUTER_MIN_BLOCKS_BWD);
   const int64_t ntj = (n_j + V3_OUTER_J - 1) / V3_OUTER_J, nti = (n_i + 4 * rpw - 1) / (4 * rpw);
   return (ntj * n_i * 2 + nti * n_j * 6) * (dtype == VMF_F32 ? 4 : 8);
 }
@@ -512,15 +559,15 @@ static void launch_outer_bwd(const V3Call& c, int64_t n_i, int64_t n_j, int ntj,
   else V3_GO(false);
 #undef V3_GO
   const int64_t nmax = n_i > n_j ? n_i : n_j;
-  hipLaunchKernelGGL((vmf3_outer_bwd_finish_kernel<T, MP>), dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, c.stream,
-                     (const T*)c.loc, (const T*)c.scale, (const T*)c.u, (const T*)c.eps, (const T*)c.gkappa, rowp, colp,
+  hipLaunchKernelGGL((vmf3_outer_bwd_finish_kernel<T, MP>), dim3((unsigned)((nmax + V3_FIN_IDX - 1) / V3_FIN_IDX)), dim3(256), 0,
+                     c.stream, (const T*)c.loc, (const T*)c.scale, (const T*)c.u, (const T*)c.eps, (const T*)c.gkappa, rowp, colp,
                      (T*)c.dloc, (T*)c.dscale, n_i, n_j, ntj, nti, c.softplus, c.ka);
 }
 
 int vmf3_bwd_outer(const V3Call& c, int64_t n_i, int64_t n_j, void* workspace, int64_t workspace_bytes) {
   int ntj, rpw;
   int64_t nti;
-  int rc = outer_grid(n_i, n_j, &ntj, &nti, &rpw, "vmf3_rsample_bwd_outer");
+  int rc = outer_grid(n_i, n_j, VMF3_OUTER_MIN_BLOCKS_BWD, &ntj, &nti, &rpw, "vmf3_rsample_bwd_outer");
   if (rc) return rc;
   const int64_t need = vmf3_bwd_outer_workspace_bytes(n_i, n_j, c.dtype);
   VMF_REQUIRE(workspace && workspace_bytes >= need && v3_aligned16(workspace), VMF_ERR_BAD_ARG,

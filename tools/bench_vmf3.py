@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The m = 3 reference-exact kernels through the C ABI, kernel time only (HIP events around the launches, tensors
 resident): the row-per-row shape at 2^24 rows and the (B, 1)-scale outer product at B = 4096 and 128, forward and
-backward, fp32.  Prints a markdown table; run on the GPU box:  python tools/bench_vmf3.py"""
+backward, fp32.  Prints a markdown table; run on the GPU box:  python tools/bench_vmf3.py [--outer-only] [--reps N]
+(--reps 3 under rocprofv3 --pmc)."""
 import ctypes as C
 import os
 import sys
@@ -18,7 +19,12 @@ from medicalimageanalysis_amd.sampler.von_mises_fisher import vmf3_broadcast_pla
 DEV = torch.device("cuda:0")
 
 
-def timeit(fn, reps=20, warm=10):
+REPS = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 20
+
+
+def timeit(fn, reps=None, warm=None):
+    reps = reps or REPS
+    warm = min(10, reps) if warm is None else warm
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -89,7 +95,7 @@ def main():
         torch.cuda.empty_cache()
 
     n = 1 << 24
-    for given in (False, True):
+    for given in ((False, True) if "--outer-only" not in sys.argv else ()):
         nz = 16 if given else 0
         case(f"rows, B = 2^24 -> (B, 3)", (n, 3), (n,), given, n * (28 + nz), n * (44 + nz))
     for B in (4096, 128):

@@ -5,6 +5,9 @@
   python tools/summarise_profiles.py pmc    gpurun_out/pmc_fetch gpurun_out/pmc_write [more pmc dirs] \
          --rows 16777216 --m 64 --out profiles/traffic_latest.json --csv profiles/NAME_pmc.csv
 
+  python tools/summarise_profiles.py pmcall gpurun_out/pmc_A gpurun_out/pmc_B ... profiles/NAME.csv  # every kernel,
+         one line per (kernel, grid size): mean counter values per dispatch, HBM bytes corrected as below
+
 HBM traffic follows the gfx950 rules for rocprofv3: FETCH_SIZE and WRITE_SIZE are reported in KiB by separate
 passes; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream, so it is doubled; WRITE_SIZE is
 exact for 16-B-per-lane streaming stores.
@@ -68,9 +71,33 @@ def pmc(dirs, rows, m, out_json, out_csv, log_prob=True, kernel="vmf_rsample_fwd
     print(json.dumps(res))
 
 
+def pmcall(dirs, out_csv):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                name = r["Kernel_Name"]
+                if name.startswith("void at::") or "elementwise_kernel" in name or "distribution" in name:
+                    continue  # torch's own fills and random inputs of the bench script
+                agg[(name[:90], r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    names = sorted({c for v in agg.values() for c in v})
+    with open(out_csv, "w", newline="") as out:
+        w = csv.writer(out)
+        w.writerow(["kernel(truncated)", "grid_threads", "dispatches"] + names + ["hbm_read_bytes(FETCH_SIZE*1024*2)",
+                                                                               "hbm_write_bytes(WRITE_SIZE*1024)"])
+        for (k, g), v in sorted(agg.items()):
+            mean = {c: sum(x) / len(x) for c, x in v.items()}
+            w.writerow([k, g, max(len(x) for x in v.values())] + [f"{mean[c]:.6g}" if c in mean else "" for c in names] +
+                       [f"{mean['FETCH_SIZE'] * 2048:.6g}" if "FETCH_SIZE" in mean else "",
+                        f"{mean['WRITE_SIZE'] * 1024:.6g}" if "WRITE_SIZE" in mean else ""])
+    print("wrote", out_csv)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "pmcall":
+        pmcall(sys.argv[2:-1], sys.argv[-1])
     else:
         ap = argparse.ArgumentParser()
         ap.add_argument("mode")
