@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VMF_HIP_VERSION 130
+#define VMF_HIP_VERSION 131
 
 typedef void* vmf_stream_t; /* hipStream_t */
 
@@ -276,6 +276,18 @@ int vmf_latent_loss_fwd(const void* z, const void* labels, void* per_row_out, vo
 int vmf_latent_loss_bwd(const void* z, const void* labels, const void* grad_mean, void* dz, int64_t n, int zdim,
                         int64_t n_labels, int label_cols, int variant, double R, double r, int dtype,
                         vmf_stream_t stream);
+
+/* ---- multi-GPU ---------------------------------------------------------------------------------------
+ * The path shards by row and exchanges nothing but loss scalars: the `.mean()` / `.sum()` of
+ * model/spherical_vae.py:134,136 and regular_cnn/s1_vae.py:75,90 taken over all ranks' rows.  buf (device, `count`
+ * doubles, e.g. [sum KL, sum reconstruction, sum log p, rows]) is summed over the ranks of `comm` (an ncclComm_t of
+ * the RCCL library loaded in the process) in place, asynchronously on `stream`; divide by the summed row count
+ * afterwards.  The reference is single-device (model/train.py:36-37) and has no counterpart. */
+#define VMF_ALLREDUCE_MAX_SCALARS 64
+int vmf_allreduce_scalars(void* comm, double* buf, int count, vmf_stream_t stream);
+
+/* Every compute entry point opens a marker range of its own name when the environment has VMF_ROCTX=1
+ * (`rocprofv3 --marker-trace`); no other observable state. */
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,15 @@ int vmf_check_launch(const char* what);
     }                                  \
   } while (0)
 
+// Marker range around an entry point, visible in `rocprofv3 --marker-trace`.  Off unless the environment has
+// VMF_ROCTX=1; the marker library is looked up at run time, so the shared library links the HIP runtime only.
+struct VmfRange {
+  explicit VmfRange(const char* name);
+  ~VmfRange();
+  bool on;
+};
+#define VMF_RANGE(name) VmfRange vmf_range_guard_(name)
+
 // Launches `expr` once with T = float or double.
 #define VMF_DISPATCH_DTYPE(dtype, ...)                    \
   do {                                                    \

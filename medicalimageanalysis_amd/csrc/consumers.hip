@@ -145,6 +145,7 @@ static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 extern "C" int vmf_elbo_fwd(const void* x, const void* x_hat, const void* kappa, void* loss_out, double* parts_out,
                             double* workspace, double a_rec, double a_kl, int64_t n_x, int64_t n_hat,
                             int64_t n_kappa, int variant, int dtype, vmf_stream_t stream) {
+  VMF_RANGE("vmf_elbo_fwd");
   VMF_REQUIRE(n_x > 0 && n_hat >= 0 && n_kappa >= 0, VMF_ERR_BAD_ARG, "vmf_elbo_fwd: bad sizes");
   VMF_REQUIRE(n_hat % n_x == 0, VMF_ERR_BAD_ARG, "vmf_elbo_fwd: n_hat %lld is not a multiple of n_x %lld",
               (long long)n_hat, (long long)n_x);
@@ -178,6 +179,7 @@ extern "C" int vmf_elbo_fwd(const void* x, const void* x_hat, const void* kappa,
 extern "C" int vmf_elbo_bwd(const void* x, const void* x_hat, const void* kappa, const void* grad_loss,
                             void* d_x_hat, void* d_kappa, double a_rec, double a_kl, int64_t n_x, int64_t n_hat,
                             int64_t n_kappa, int variant, int dtype, vmf_stream_t stream) {
+  VMF_RANGE("vmf_elbo_bwd");
   VMF_REQUIRE(n_x > 0 && n_hat >= 0 && n_kappa >= 0, VMF_ERR_BAD_ARG, "vmf_elbo_bwd: bad sizes");
   VMF_REQUIRE(n_hat % n_x == 0, VMF_ERR_BAD_ARG, "vmf_elbo_bwd: n_hat is not a multiple of n_x");
   VMF_REQUIRE(variant >= 0 && variant <= VMF_KL_STABLE_M2, VMF_ERR_BAD_ARG, "unknown KL variant %d", variant);
@@ -236,6 +238,7 @@ __global__ __launch_bounds__(256) void build_torus_kernel(const T* __restrict__ 
 
 extern "C" int vmf_build_torus_fwd(const void* z_theta, const void* z_phi, void* out, int64_t n, int zdim, double R,
                                    double r, int dtype, vmf_stream_t stream) {
+  VMF_RANGE("vmf_build_torus_fwd");
   VMF_REQUIRE(n >= 0 && zdim >= 2, VMF_ERR_BAD_ARG, "vmf_build_torus_fwd: n %lld, zdim %d", (long long)n, zdim);
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(z_theta && z_phi && out, VMF_ERR_BAD_ARG, "vmf_build_torus_fwd: null pointer");
@@ -250,6 +253,7 @@ extern "C" int vmf_build_torus_fwd(const void* z_theta, const void* z_phi, void*
 extern "C" int vmf_build_torus_bwd(const void* z_theta, const void* z_phi, const void* grad_out, void* g_theta,
                                    void* g_phi, int64_t n, int zdim, double R, double r, int dtype,
                                    vmf_stream_t stream) {
+  VMF_RANGE("vmf_build_torus_bwd");
   VMF_REQUIRE(n >= 0 && zdim >= 2, VMF_ERR_BAD_ARG, "vmf_build_torus_bwd: n %lld, zdim %d", (long long)n, zdim);
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(z_theta && z_phi && grad_out && g_theta && g_phi, VMF_ERR_BAD_ARG, "vmf_build_torus_bwd: null pointer");
@@ -336,6 +340,7 @@ static int latent_loss_check(const char* who, int64_t n, int zdim, int64_t n_lab
 extern "C" int vmf_latent_loss_fwd(const void* z, const void* labels, void* per_row_out, void* mean_out,
                                    double* workspace, int64_t n, int zdim, int64_t n_labels, int label_cols,
                                    int variant, double R, double r, int dtype, vmf_stream_t stream) {
+  VMF_RANGE("vmf_latent_loss_fwd");
   int rc = latent_loss_check("vmf_latent_loss_fwd", n, zdim, n_labels, label_cols, variant);
   if (rc) return rc;
   VMF_REQUIRE(dtype == VMF_F32 || dtype == VMF_F64, VMF_ERR_DTYPE, "dtype %d", dtype);
@@ -359,6 +364,7 @@ extern "C" int vmf_latent_loss_fwd(const void* z, const void* labels, void* per_
 extern "C" int vmf_latent_loss_bwd(const void* z, const void* labels, const void* grad_mean, void* dz, int64_t n,
                                    int zdim, int64_t n_labels, int label_cols, int variant, double R, double r,
                                    int dtype, vmf_stream_t stream) {
+  VMF_RANGE("vmf_latent_loss_bwd");
   int rc = latent_loss_check("vmf_latent_loss_bwd", n, zdim, n_labels, label_cols, variant);
   if (rc) return rc;
   if (n == 0) return VMF_OK;

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void bessel_ratio_kernel(const T* __restrict__
 }
 
 extern "C" int vmf_ive_fwd(double v, const void* z, void* out, int64_t n, int dtype, vmf_stream_t stream) {
+  VMF_RANGE("vmf_ive_fwd");
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(z && out, VMF_ERR_BAD_ARG, "vmf_ive_fwd: null pointer");
@@ -65,6 +66,7 @@ extern "C" int vmf_ive_fwd(double v, const void* z, void* out, int64_t n, int dt
 
 extern "C" int vmf_ive_bwd(double v, const void* z, const void* gout, void* gz, int64_t n, int dtype,
                            vmf_stream_t stream) {
+  VMF_RANGE("vmf_ive_bwd");
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(z && gout && gz, VMF_ERR_BAD_ARG, "vmf_ive_bwd: null pointer");
@@ -78,6 +80,7 @@ extern "C" int vmf_ive_bwd(double v, const void* z, const void* gout, void* gz, 
 }
 
 extern "C" int vmf_log_ive_fwd(double v, const void* z, void* out, int64_t n, int dtype, vmf_stream_t stream) {
+  VMF_RANGE("vmf_log_ive_fwd");
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
   VMF_REQUIRE(v >= 0, VMF_ERR_UNSUPPORTED, "vmf_log_ive_fwd: order %g < 0", v);
   if (n == 0) return VMF_OK;
@@ -91,6 +94,7 @@ extern "C" int vmf_log_ive_fwd(double v, const void* z, void* out, int64_t n, in
 
 extern "C" int vmf_bessel_ratio_fwd(double v, const void* z, void* out, int64_t n, int dtype,
                                     vmf_stream_t stream) {
+  VMF_RANGE("vmf_bessel_ratio_fwd");
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
   VMF_REQUIRE(v >= 1.0, VMF_ERR_UNSUPPORTED, "vmf_bessel_ratio_fwd: order %g < 1", v);
   if (n == 0) return VMF_OK;
@@ -246,6 +250,7 @@ static int kl_fwd_launch(const char* who, const void* kappa, void* out, double* 
 
 extern "C" int vmf_kl_fwd(const void* kappa, void* out, double* sum_out, double* workspace, double alpha,
                           int64_t n, int variant, int dtype, vmf_stream_t stream) {
+  VMF_RANGE("vmf_kl_fwd");
   return kl_fwd_launch("vmf_kl_fwd", kappa, out, sum_out, workspace, alpha, n, variant, dtype, (hipStream_t)stream);
 }
 
@@ -284,6 +289,7 @@ static int kl_static_scratch(double** ptr_out) {
 
 extern "C" int vmf_kl_fwd_static(const void* kappa, void* out, double* sum_out, double alpha, int64_t n, int variant,
                                  int dtype, vmf_stream_t stream) {
+  VMF_RANGE("vmf_kl_fwd_static");
   VMF_REQUIRE(n <= VMF_KL_STATIC_MAX_N, VMF_ERR_UNSUPPORTED,
               "vmf_kl_fwd_static: n=%lld exceeds VMF_KL_STATIC_MAX_N=%lld (use vmf_kl_fwd with a caller workspace)",
               (long long)n, (long long)VMF_KL_STATIC_MAX_N);
@@ -298,6 +304,7 @@ extern "C" int vmf_kl_fwd_static(const void* kappa, void* out, double* sum_out, 
 
 extern "C" int vmf_kl_bwd(const void* kappa, const void* gout, int64_t gout_stride, double gscale, void* dkappa,
                           int64_t n, int variant, int dtype, vmf_stream_t stream) {
+  VMF_RANGE("vmf_kl_bwd");
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
   VMF_REQUIRE(variant >= 0 && variant <= VMF_KL_STABLE_M2, VMF_ERR_BAD_ARG, "unknown KL variant %d", variant);
   VMF_REQUIRE(gout_stride == 0 || gout_stride == 1, VMF_ERR_BAD_ARG, "gout_stride must be 0 or 1");
@@ -366,6 +373,7 @@ __global__ __launch_bounds__(256) void sphere_uniform_kernel(const T* __restrict
 extern "C" int vmf_sphere_uniform_sample(const void* gauss, void* out, int64_t n, int dim, uint64_t row0,
                                          uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int dtype,
                                          vmf_stream_t stream) {
+  VMF_RANGE("vmf_sphere_uniform_sample");
   VMF_REQUIRE(n >= 0 && dim >= 1, VMF_ERR_BAD_ARG, "bad n/dim");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(out, VMF_ERR_BAD_ARG, "vmf_sphere_uniform_sample: null out");
@@ -467,6 +475,7 @@ static bool pair_aligned(const void* p) { return ((uintptr_t)p & (2 * sizeof(T) 
 extern "C" int vmf_s1_projnormal_fwd(const void* mean, const void* kappa, const void* noise, void* z, int64_t n,
                                      int dim, uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                                      int dtype, vmf_stream_t stream) {
+  VMF_RANGE("vmf_s1_projnormal_fwd");
   VMF_REQUIRE(n >= 0 && dim >= 1, VMF_ERR_BAD_ARG, "bad n/dim");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(mean && kappa && z, VMF_ERR_BAD_ARG, "vmf_s1_projnormal_fwd: null pointer");
@@ -490,6 +499,7 @@ extern "C" int vmf_s1_projnormal_fwd(const void* mean, const void* kappa, const 
 extern "C" int vmf_s1_projnormal_bwd(const void* mean, const void* kappa, const void* noise, const void* gz,
                                      void* dmean, void* dkappa, int64_t n, int dim, uint64_t row0, uint64_t seed,
                                      uint64_t offset, const uint64_t* offset_dev, int dtype, vmf_stream_t stream) {
+  VMF_RANGE("vmf_s1_projnormal_bwd");
   VMF_REQUIRE(n >= 0 && dim >= 1, VMF_ERR_BAD_ARG, "bad n/dim");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(mean && kappa && gz && dmean && dkappa, VMF_ERR_BAD_ARG, "vmf_s1_projnormal_bwd: null pointer");

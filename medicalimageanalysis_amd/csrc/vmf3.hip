@@ -6,8 +6,13 @@
 // the reference's models produce -- one row per (loc, scale) pair, and the (B, 1)-scale outer product (B, B, 3) --
 // have kernels of their own in vmf3_fast.hip; any other broadcast (sample shapes in front of shared parameters ...)
 // takes the thread-per-output-row kernels below.
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
 
 #include "vmf3_fast.h"
 #include "vmf_math.h"
@@ -28,6 +33,71 @@ int vmf_check_launch(const char* what) {
     vmf_set_error("%s: %s", what, hipGetErrorString(e));
     return VMF_ERR_LAUNCH;
   }
+  return VMF_OK;
+}
+
+// ---- marker ranges ----------------------------------------------------------------------------
+namespace {
+typedef int (*range_push_fn)(const char*);
+typedef int (*range_pop_fn)(void);
+range_push_fn g_range_push = nullptr;
+range_pop_fn g_range_pop = nullptr;
+std::once_flag g_range_once;
+
+void range_init() {
+  const char* e = getenv("VMF_ROCTX");
+  if (!e || !*e || !strcmp(e, "0")) return;
+  // rocprofv3 intercepts the markers of the SDK's library; the older tracer library is the fall-back
+  static const char* const names[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so",
+                                      "libroctx64.so.4"};
+  for (const char* n : names) {
+    void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) continue;
+    range_push_fn a = (range_push_fn)dlsym(h, "roctxRangePushA");
+    range_pop_fn b = (range_pop_fn)dlsym(h, "roctxRangePop");
+    if (a && b) {
+      g_range_push = a;
+      g_range_pop = b;
+      return;
+    }
+  }
+  fprintf(stderr, "libvmf_hip: VMF_ROCTX is set but no marker library could be loaded (%s)\n", dlerror());
+}
+}  // namespace
+
+VmfRange::VmfRange(const char* name) {
+  std::call_once(g_range_once, range_init);
+  on = g_range_push != nullptr;
+  if (on) g_range_push(name);
+}
+VmfRange::~VmfRange() {
+  if (on) g_range_pop();
+}
+
+// ---- loss scalars across ranks -------------------------------------------------------------------
+// The one exchange of the data-parallel path: a handful of doubles (sum KL, sum reconstruction, sum log p, count)
+// summed over the ranks' shards, in place, on the caller's stream.  The collective library is the one the process has
+// already loaded (the communicator comes from it); it is looked up at run time for the same reason as the markers.
+extern "C" int vmf_allreduce_scalars(void* comm, double* buf, int count, vmf_stream_t stream) {
+  VMF_RANGE("vmf_allreduce_scalars");
+  VMF_REQUIRE(comm && buf && count > 0 && count <= VMF_ALLREDUCE_MAX_SCALARS, VMF_ERR_BAD_ARG,
+              "vmf_allreduce_scalars: communicator and buffer must be non-null, 1 <= count <= %d (got %d)",
+              VMF_ALLREDUCE_MAX_SCALARS, count);
+  typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+  static allreduce_fn fn = nullptr;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    fn = (allreduce_fn)dlsym(RTLD_DEFAULT, "ncclAllReduce");
+    if (!fn) {
+      void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (h) fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
+    }
+  });
+  VMF_REQUIRE(fn, VMF_ERR_UNSUPPORTED, "vmf_allreduce_scalars: ncclAllReduce not found (is librccl loaded?)");
+  const int kFloat64 = 8, kSum = 0;  // ncclFloat64, ncclSum
+  const int rc = fn(buf, buf, (size_t)count, kFloat64, kSum, comm, (hipStream_t)stream);
+  VMF_REQUIRE(rc == 0, VMF_ERR_LAUNCH, "vmf_allreduce_scalars: ncclAllReduce returned %d", rc);
   return VMF_OK;
 }
 
@@ -222,6 +292,7 @@ extern "C" int vmf3_rsample_fwd(const void* loc, const void* scale, const void* 
                                 void* w_out, void* kappa_out, int ndim, const int64_t* odims, const int64_t* w_str,
                                 const int64_t* k_str, const int64_t* l_str, const int64_t* e_str, int flags, int dtype,
                                 uint64_t seed, uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream) {
+  VMF_RANGE("vmf3_rsample_fwd");
   Bcast bc;
   int64_t n_out = 0;
   int rc = make_bcast(&bc, &n_out, ndim, odims, w_str, k_str, l_str, e_str);
@@ -258,6 +329,7 @@ extern "C" int vmf3_rsample_bwd(const void* loc, const void* scale, const void* 
                                 int64_t n_scale, int ndim, const int64_t* odims, const int64_t* w_str,
                                 const int64_t* k_str, const int64_t* l_str, const int64_t* e_str, int flags, int dtype,
                                 uint64_t seed, uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream) {
+  VMF_RANGE("vmf3_rsample_bwd");
   Bcast bc;
   int64_t n_out = 0;
   int rc = make_bcast(&bc, &n_out, ndim, odims, w_str, k_str, l_str, e_str);
@@ -313,6 +385,7 @@ extern "C" int vmf3_rsample_bwd_outer(const void* loc, const void* scale, const 
                                       int64_t n_i, int64_t n_j, void* workspace, int64_t workspace_bytes, int flags,
                                       int dtype, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                                       vmf_stream_t stream) {
+  VMF_RANGE("vmf3_rsample_bwd_outer");
   VMF_REQUIRE(n_i >= 0 && n_j >= 0, VMF_ERR_BAD_ARG, "vmf3_rsample_bwd_outer: negative size");
   VMF_REQUIRE(dtype == VMF_F32 || dtype == VMF_F64, VMF_ERR_DTYPE, "dtype %d", dtype);
   VMF_REQUIRE((flags & ~VMF_FLAG_SOFTPLUS_KAPPA) == 0, VMF_ERR_BAD_ARG, "vmf3_rsample_bwd_outer: unknown flags %d", flags);
@@ -351,6 +424,7 @@ __global__ __launch_bounds__(256) void vmf3_w_kernel(const T* __restrict__ scale
 
 extern "C" int vmf3_sample_w_fwd(const void* scale, const void* u, void* w, int64_t n, int64_t n_scale, int dtype,
                                  uint64_t seed, uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream) {
+  VMF_RANGE("vmf3_sample_w_fwd");
   VMF_REQUIRE(n >= 0 && n_scale >= 0, VMF_ERR_BAD_ARG, "vmf3_sample_w_fwd: negative size");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(n_scale > 0 && n % n_scale == 0, VMF_ERR_BAD_ARG, "vmf3_sample_w_fwd: n %lld does not tile n_scale %lld",
@@ -373,6 +447,7 @@ extern "C" int vmf3_sample_w_fwd(const void* scale, const void* u, void* w, int6
 extern "C" int vmf3_sample_w_bwd(const void* scale, const void* u, const void* grad_w, void* dscale_rows, int64_t n,
                                  int64_t n_scale, int dtype, uint64_t seed, uint64_t offset,
                                  const uint64_t* offset_dev, vmf_stream_t stream) {
+  VMF_RANGE("vmf3_sample_w_bwd");
   VMF_REQUIRE(n >= 0 && n_scale >= 0, VMF_ERR_BAD_ARG, "vmf3_sample_w_bwd: negative size");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(n_scale > 0 && n % n_scale == 0, VMF_ERR_BAD_ARG, "vmf3_sample_w_bwd: n does not tile n_scale");
@@ -415,6 +490,7 @@ __global__ __launch_bounds__(256) void vmf3_log_prob_ref_kernel(const T* __restr
 
 extern "C" int vmf3_log_prob_ref(const void* loc, const void* scale, const void* x, void* logp, void* lognorm,
                                  int64_t n, int dtype, vmf_stream_t stream) {
+  VMF_RANGE("vmf3_log_prob_ref");
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(scale && (!logp || (loc && x)), VMF_ERR_BAD_ARG, "vmf3_log_prob_ref: null pointer");
@@ -459,6 +535,7 @@ __global__ __launch_bounds__(256) void vmf3_log_prob_ref_bwd_kernel(const T* __r
 
 extern "C" int vmf3_log_prob_ref_bwd(const void* loc, const void* scale, const void* x, const void* gl, void* dloc,
                                      void* dscale, void* dx, int64_t n, int dtype, vmf_stream_t stream) {
+  VMF_RANGE("vmf3_log_prob_ref_bwd");
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(loc && scale && x && gl, VMF_ERR_BAD_ARG, "vmf3_log_prob_ref_bwd: null pointer");
@@ -487,6 +564,7 @@ __global__ __launch_bounds__(256) void vmf3_mean_kernel(const T* __restrict__ lo
 
 extern "C" int vmf3_mean(const void* loc, const void* scale, void* mean, int64_t n, int dtype,
                          vmf_stream_t stream) {
+  VMF_RANGE("vmf3_mean");
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(loc && scale && mean, VMF_ERR_BAD_ARG, "vmf3_mean: null pointer");

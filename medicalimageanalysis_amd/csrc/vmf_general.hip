@@ -955,6 +955,7 @@ extern "C" int vmf_rsample_fwd(const void* mu, int64_t mu_stride, const void* ka
                                int64_t n, int m, const void* prop_e, const void* prop_u, int n_prop, const void* gauss,
                                int max_prop, uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                                int flags, int dtype, vmf_stream_t stream) {
+  VMF_RANGE("vmf_rsample_fwd");
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
   VMF_REQUIRE((flags & ~(VMF_FLAG_NORMALIZE_MU | VMF_FLAG_SOFTPLUS_KAPPA)) == 0, VMF_ERR_BAD_ARG,
               "vmf_rsample_fwd: unknown flags %d", flags);
@@ -1019,6 +1020,7 @@ extern "C" int vmf_rsample_bwd(const void* mu, int64_t mu_stride, const void* ka
                                const void* grad_kappa, void* dmu, void* dkappa, int64_t n, int m, uint64_t row0,
                                uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int flags, int dtype,
                                vmf_stream_t stream) {
+  VMF_RANGE("vmf_rsample_bwd");
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
   VMF_REQUIRE((flags & ~(VMF_FLAG_NORMALIZE_MU | VMF_FLAG_SOFTPLUS_KAPPA)) == 0, VMF_ERR_BAD_ARG,
               "vmf_rsample_bwd: unknown flags %d", flags);
@@ -1145,6 +1147,7 @@ static int log_prob_t(const void* mu, int64_t mu_stride, const void* kappa, int6
 
 extern "C" int vmf_log_prob_fwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride,
                                 const void* x, void* logp, int64_t n, int m, int dtype, vmf_stream_t stream) {
+  VMF_RANGE("vmf_log_prob_fwd");
   VMF_REQUIRE(n >= 0 && m >= 2, VMF_ERR_BAD_ARG, "bad n/m");
   VMF_REQUIRE(m <= 2048, VMF_ERR_UNSUPPORTED, "m=%d > 2048 is not supported", m);
   VMF_REQUIRE(kappa_stride == 0 || kappa_stride == 1, VMF_ERR_BAD_ARG, "kappa_stride must be 0 or 1");
@@ -1161,6 +1164,7 @@ extern "C" int vmf_log_prob_fwd(const void* mu, int64_t mu_stride, const void* k
 extern "C" int vmf_log_prob_bwd(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride,
                                 const void* x, const void* gl, void* dmu, void* dx, void* dkappa, int64_t n, int m,
                                 int dtype, vmf_stream_t stream) {
+  VMF_RANGE("vmf_log_prob_bwd");
   VMF_REQUIRE(n >= 0 && m >= 2, VMF_ERR_BAD_ARG, "bad n/m");
   VMF_REQUIRE(m <= 2048, VMF_ERR_UNSUPPORTED, "m=%d > 2048 is not supported", m);
   VMF_REQUIRE(kappa_stride == 0 || kappa_stride == 1, VMF_ERR_BAD_ARG, "kappa_stride must be 0 or 1");
@@ -1192,6 +1196,7 @@ __global__ __launch_bounds__(256) void vmf_entropy_kl_kernel(const T* __restrict
 
 extern "C" int vmf_entropy_kl_fwd(const void* kappa, void* entropy, void* kl, void* dkl_dk, int64_t n, int m,
                                   int dtype, vmf_stream_t stream) {
+  VMF_RANGE("vmf_entropy_kl_fwd");
   VMF_REQUIRE(n >= 0 && m >= 2, VMF_ERR_BAD_ARG, "bad n/m");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(kappa, VMF_ERR_BAD_ARG, "vmf_entropy_kl_fwd: null kappa");

@@ -393,3 +393,30 @@ def test_c_abi_driver_without_python_runs_the_headline_kernel():
     assert out["self_check"] == "ok" and out["rows"] == 1 << 20 and out["kernel_ms_min"] > 0
     run = subprocess.run([exe, "1000", "10", "2", "1"], capture_output=True, text=True, timeout=100)   # scalar-access shape
     assert run.returncode == 0, run.stdout + run.stderr
+
+
+def test_allreduce_scalars_through_a_one_rank_rccl_communicator():
+    """vmf_allreduce_scalars against a communicator made with RCCL's own C API (the library torch ships): with one
+    rank the sum leaves the packed buffer unchanged; the call is asynchronous on the given stream."""
+    import os
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(DEV)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        vals = [1.5, 2.5, -3.0, 128.0]
+        buf = torch.tensor(vals, device=DEV, dtype=torch.float64)
+        rc = _lib.lib().vmf_allreduce_scalars(comm, _lib.ptr(buf), 4, _lib.stream_ptr(DEV))
+        assert rc == 0, _lib.lib().vmf_last_error_string()
+        torch.cuda.synchronize()
+        assert buf.tolist() == vals
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)

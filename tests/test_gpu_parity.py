@@ -99,7 +99,7 @@ def close_vmf3(z, z_ref, tag, loc, scale, u, eps, ss=(), name="vmf3"):
 
 def test_library_loaded_is_in_tree():
     assert os.path.dirname(_lib.library_path()).endswith("medicalimageanalysis_amd")
-    assert _lib.lib().vmf_version() == 130
+    assert _lib.lib().vmf_version() == 131
 
 
 # ---- VonMisesFisher3D ---------------------------------------------------------------------------------------

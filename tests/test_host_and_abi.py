@@ -24,7 +24,7 @@ def test_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(h, name), name
     lib = _lib.lib()
-    assert lib.vmf_version() == 130
+    assert lib.vmf_version() == 131
     # argument errors are reported without touching a GPU
     assert lib.vmf_rsample_fwd(None, 64, None, 1, None, None, None, None, None, None, -1, 64, None, None, 0, None, 64, 0, 0, 0, None, 0,
                                0, None) == -1
@@ -331,3 +331,33 @@ def test_bench_fails_when_a_rank_fails():
     out = _run_bench("--gpus", "2", "--rows", "4096", "--cpu-rows", "0", "--steps", "1", "--warmup", "0", "--backend",
                      "no-such-backend")
     assert out.returncode != 0
+
+
+def test_marker_ranges_load_the_marker_library_only_when_asked():
+    """VMF_ROCTX=1: the first entry point (here one that returns on its argument check, no GPU touched) looks the
+    marker library up; without the variable nothing of the kind is mapped."""
+    code = ("import ctypes, os, sys; sys.path.insert(0, %r)\n"
+            "from medicalimageanalysis_amd import _lib\n"
+            "rc = _lib.lib().vmf_ive_fwd(0.5, None, None, -1, 0, None)\n"
+            "maps = open('/proc/self/maps').read()\n"
+            "print(rc, int('rocprofiler-sdk-roctx' in maps))\n") % ROOT
+    for flag, want in (("1", "1"), ("0", "0"), (None, "0")):
+        env = dict(os.environ)
+        env.pop("VMF_ROCTX", None)
+        if flag is not None:
+            env["VMF_ROCTX"] = flag
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        rc, loaded = out.stdout.split()
+        assert int(rc) < 0 and loaded == want, (flag, out.stdout, out.stderr)
+
+
+def test_allreduce_scalars_argument_checks():
+    from medicalimageanalysis_amd import _lib
+    lib = _lib.lib()
+    buf = (C.c_double * 4)()
+    assert lib.vmf_allreduce_scalars(None, buf, 4, None) == -1
+    assert lib.vmf_allreduce_scalars(C.c_void_p(1), None, 4, None) == -1
+    assert lib.vmf_allreduce_scalars(C.c_void_p(1), buf, 0, None) == -1
+    assert lib.vmf_allreduce_scalars(C.c_void_p(1), buf, 65, None) == -1
+    assert b"count" in lib.vmf_last_error_string()
