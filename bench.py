@@ -53,8 +53,8 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     # the GPU needs ~10 launches of the headline size to settle its clocks (per-dispatch times in profiles/: 2.2, 2.0,
     # 1.9 ... then 1.53-1.56 ms), hence the default warm-up
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=3, choices=[1, 2, 3, 4, 5])
     ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default: the configuration's own size)")
     ap.add_argument("--m", type=int, default=None, help="ambient dimension for configs 3 / 4")
@@ -185,8 +185,8 @@ class GeneralRSample:
         assert torch.isfinite(nrm).all() and float((nrm - 1).abs().max()) < 1e-3, "rsample produced non-unit rows"
 
     def copy_GBps(self):
-        """what a plain device copy of the same 2 x n x m x 4 bytes reaches on this GPU (outside the timed region; the
-        output buffer is scratch by now)"""
+        """what a plain device copy of the same 2 x n x m x 4 bytes reaches on this GPU (before the warm-up steps, outside
+        the timed region)"""
         cev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
         self.z.copy_(self.mu)
         for s_, e_ in cev:
@@ -547,6 +547,11 @@ def run_rank(a):
             dist.all_reduce(scalars)
 
     do_ar = a.with_allreduce and use_dist
+    # The roofline's yardstick -- a plain device copy of the same buffers -- is measured first, while the output buffer is
+    # still scratch.  It also spares the timed steps most of the launch-time transient that follows an idle period on
+    # this GPU (tools/clock_probe.py: from idle, launches 2..12 of the headline kernel run 1.6-2.1 ms before settling at
+    # 1.54; with a handful of copies in front they run 1.55-1.7).
+    copy = wl.copy_GBps() if gpu else None
     for i in range(a.warmup):
         wl.step(i, None)
         if do_ar:
@@ -624,7 +629,6 @@ def run_rank(a):
                                           + "; not re-measured in this run")
                 except (OSError, ValueError):
                     pass
-            copy = wl.copy_GBps()
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                                "kernel": wl.kernel, "kernel_ms": kern_ms, "kernel_ms_min": float(np.min(kern_all)),

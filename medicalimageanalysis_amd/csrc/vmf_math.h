@@ -288,7 +288,8 @@ VMF_HD void kl_m3_eps_fast(float k, float eps, float* kl, float* g, bool finite_
     const float em = fast_exp2(-1.44269504088896340736f * k), e2 = em * em;
     const float D = 1.0f - e2 + 2.0f * eps * em;
     const float rD = fast_rcp(D);
-    *kl = fast_log(k) + (0.69314718055994530942f - 1.0f) - fast_log(D) + 2.0f * k * (e2 - eps * em) * rD;
+    // log k - log D as one logarithm: these kernels are bound by the quarter-rate transcendental instructions
+    *kl = fast_log(k * rD) + (0.69314718055994530942f - 1.0f) + 2.0f * k * (e2 - eps * em) * rD;
     *g = fast_rcp(k) + k * (2.0f * eps * em * (1.0f - e2) - 4.0f * e2) * (rD * rD);
     return;
   }
@@ -417,8 +418,10 @@ VMF_HD bool kl_value_fast(float kappa, int variant, float* kl_out, float* grad) 
 }
 
 // KL(vM(kappa) || U(S^1)) = kappa I1/I0 - log I0, the VALUE alone (what the fused sums and the per-element forward
-// need), from polynomial fits of the function itself: one Horner chain of 11 / 17 / 13 terms per element instead of the
-// two Chebyshev series (20 + 29 or 8 + 11 terms at two instructions each) that the value-and-derivative form evaluates.
+// need), from polynomial fits of the function itself: one Horner chain of 12 (a <= 3) or 17 (a > 3) terms per element
+// instead of the two Chebyshev series (20 + 29 or 8 + 11 terms at two instructions each) that the value-and-derivative
+// form evaluates.  Two intervals, not more: a wave of mixed concentrations runs every chain, so the sum of the chain
+// lengths is the cost (packed v_pk_fma_f32 pairs were tried for a branch-free form and issue at half rate here: slower).
 template <int n>
 VMF_HD float horner_f32(const float (&c)[n], float t) {
   float acc = c[n - 1];
@@ -427,13 +430,12 @@ VMF_HD float horner_f32(const float (&c)[n], float t) {
   return acc;
 }
 VMF_HD float kl_m2_value_f32(float a) {  // a = |kappa|, finite
-  if (a <= 2.0f) {
+  if (a <= KLM2_A0) {
     const float y = 0.25f * a * a;
-    return y * horner_f32(KLM2_S, 2.0f * y - 1.0f);
+    return y * horner_f32(KLM2_S, (8.0f / (KLM2_A0 * KLM2_A0)) * y - 1.0f);
   }
-  if (a <= 8.0f) return horner_f32(KLM2_M, (a - 5.0f) * (1.0f / 3.0f));
   const float ra = fast_rcp(a);
-  return 0.5f * fast_log(a) + KLM2_C0 + horner_f32(KLM2_L, 16.0f * ra - 1.0f);
+  return ::fmaf(0.5f * 0.69314718055994530942f, fast_log2(a), KLM2_C0) + horner_f32(KLM2_L, (2.0f * KLM2_A0) * ra - 1.0f);
 }
 
 // log C_2(k) = -log 2pi - log(I0(k) e^-k) - k for the circle, single precision, k > 0: the Chebyshev series of i0e
