@@ -21,7 +21,7 @@ import os
 import sys
 
 
-def stats(src, dst, timed_steps=50):
+def stats(src, dst, timed_steps=20):
     f = glob.glob(os.path.join(src, "**", "*_kernel_stats.csv"), recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     with open(dst, "w", newline="") as out:
