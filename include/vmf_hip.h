@@ -78,8 +78,9 @@ const char* vmf_last_error_string(void);
 /* Replaces VonMisesFisher3D.__init__'s normalisation and .rsample (sampler/von_mises_fisher.py:30, 50-86):
  *   l = loc/(||loc||+1e-5);  w = 1 + logsumexp(log u, log(1-u) - 2k)/k;  v = normalise(eps - <eps,l> l);
  *   z = w l + sqrt(clamp(1-w^2, 1e-10, 1)) v.
- * u / eps may be null: then u[i] comes from Philox(index i, slot 0) and eps row j from Philox(index j,
- * slot 1) (Box-Muller).  w_out (nullable) receives w, indexed like u; kappa_out (nullable) receives the kappa the
+ * u / eps may be null: then both come from Philox(index, slot 0) = (x, y, z, w), 23 bits per uniform: u[i] from the
+ * upper bits of x of index i; eps row j = Box-Muller(y, z) -> eps0, eps1 and Box-Muller(w, t) -> eps2 (cosine branch)
+ * of index j, t being the lower 9 bits of x, y, z side by side.  w_out (nullable) receives w, indexed like u; kappa_out (nullable) receives the kappa the
  * kernel used, indexed like scale (of interest with VMF_FLAG_SOFTPLUS_KAPPA: the KL term needs it).
  * fp32 calls evaluate log / exp / sqrt / 1/x with the 1-ulp hardware instructions, fp64 calls with the accurate
  * library.  Two broadcast shapes have kernels of their own (vmf3_broadcast_kind tells which a call is): every operand

@@ -21,7 +21,22 @@ int vmf3_fwd_outer(const V3Call& c, int64_t n_i, int64_t n_j);
 int vmf3_bwd_outer(const V3Call& c, int64_t n_i, int64_t n_j, void* workspace, int64_t workspace_bytes);
 int64_t vmf3_bwd_outer_workspace_bytes(int64_t n_i, int64_t n_j, int dtype);
 
-// noise of one row: u from Philox(index wi, slot 0), the eps row from Philox(index ei, slot 1)
+// Noise of index i comes from ONE call, Philox(i, slot 0) = (x, y, z, w) -- u01 reads the upper 23 bits of a word, so
+// five uniforms fit into the four words without sharing a bit:
+//   u    = u01(x)                                    the inverse-CDF uniform of element i of `u`
+//   eps  = Box-Muller(u01(y), u01(z)) -> eps0, eps1;  Box-Muller(u01(w), u01(t)) -> eps2 (its cosine branch),
+//          t = the lower 9 bits of x, y and z side by side (the sine branch of the second pair is not used)
+// A row-per-row call (u index = eps index) therefore pays for one Philox call per row; the two-call layout it replaces
+// (u from slot 0, eps from slot 1) made the kernel instruction-bound at half the memory rate.
+__device__ __forceinline__ uint32_t v3_fifth_word(const U4& r) {
+  return ((r.x & 0x1FFu) << 23) | ((r.y & 0x1FFu) << 14) | ((r.z & 0x1FFu) << 5);
+}
+template <typename T>
+__device__ __forceinline__ void v3_eps_of(const U4& r, T e[3]) {
+  T unused;
+  box_muller<T>(u01<T>(r.y), u01<T>(r.z), &e[0], &e[1]);
+  box_muller<T>(u01<T>(r.w), u01<T>(v3_fifth_word(r)), &e[2], &unused);
+}
 template <typename T>
 __device__ __forceinline__ T v3_draw_u(const T* u, int64_t wi, PhiloxKey key) {
   if (u) return u[wi];
@@ -29,9 +44,7 @@ __device__ __forceinline__ T v3_draw_u(const T* u, int64_t wi, PhiloxKey key) {
 }
 template <typename T>
 __device__ __forceinline__ void v3_philox_eps(int64_t ei, PhiloxKey key, T e[3]) {
-  T n4[4];
-  philox_normal4<T>((uint64_t)ei, 1u, key, n4);
-  e[0] = n4[0]; e[1] = n4[1]; e[2] = n4[2];
+  v3_eps_of<T>(philox4x32_10((uint64_t)ei, 0u, key), e);
 }
 template <typename T>
 __device__ __forceinline__ void v3_draw_eps(const T* eps, int64_t ei, PhiloxKey key, T e[3]) {
@@ -40,4 +53,20 @@ __device__ __forceinline__ void v3_draw_eps(const T* eps, int64_t ei, PhiloxKey 
     return;
   }
   v3_philox_eps<T>(ei, key, e);
+}
+// u and the eps row of the same index: one call serves both
+template <typename T>
+__device__ __forceinline__ void v3_draw_row(const T* u, const T* eps, int64_t row, PhiloxKey key, T* uq, T e[3]) {
+  if (u && eps) {
+    *uq = u[row];
+    e[0] = eps[3 * row]; e[1] = eps[3 * row + 1]; e[2] = eps[3 * row + 2];
+    return;
+  }
+  const U4 r = philox4x32_10((uint64_t)row, 0u, key);
+  *uq = u ? u[row] : u01<T>(r.x);
+  if (eps) {
+    e[0] = eps[3 * row]; e[1] = eps[3 * row + 1]; e[2] = eps[3 * row + 2];
+  } else {
+    v3_eps_of<T>(r, e);
+  }
 }

@@ -147,8 +147,12 @@ __global__ __launch_bounds__(256) void vmf3_rows_kernel(const T* __restrict__ lo
       const int64_t row = row0 + 4 * lane + q;
       T sig = (T)1;
       kap[q] = softplus ? v3_softplus_kappa<T, MP>(k[q], &sig) : k[q];
-      const T uq = u ? uu[q] : u01<T>(philox4x32_10((uint64_t)row, 0u, key).x);
-      if (!eps) v3_philox_eps<T>(row, key, &e[3 * q]);
+      T uq = uu[q];
+      if (!u || !eps) {  // in-kernel noise: one Philox call per row serves u and the eps row
+        const U4 pr = philox4x32_10((uint64_t)row, 0u, key);
+        if (!u) uq = u01<T>(pr.x);
+        if (!eps) v3_eps_of<T>(pr, &e[3 * q]);
+      }
       if (!BWD) {
         v3_forward_row<T, MP>(&r[3 * q], kap[q], uq, &e[3 * q], &o3[3 * q], &o1[q]);
       } else {
@@ -169,9 +173,8 @@ __global__ __launch_bounds__(256) void vmf3_rows_kernel(const T* __restrict__ lo
     const T rr[3] = {loc[3 * row], loc[3 * row + 1], loc[3 * row + 2]};
     T sig = (T)1;
     const T kq = softplus ? v3_softplus_kappa<T, MP>(scale[row], &sig) : scale[row];
-    const T uq = v3_draw_u<T>(u, row, key);
-    T ee[3], o[3], s1;
-    v3_draw_eps<T>(eps, row, key, ee);
+    T uq, ee[3], o[3], s1;
+    v3_draw_row<T>(u, eps, row, key, &uq, ee);
     if (!BWD) {
       v3_forward_row<T, MP>(rr, kq, uq, ee, o, &s1);
       if (kappa_out) kappa_out[row] = kq;

@@ -96,6 +96,7 @@ struct GenParams {
   PhiloxArg ka; VmfDim dim;
   // backward only
   const T* w_in; const T* omw_in; const T* gz; T* dmu; T* dkappa;
+  int dense16;  // one-lane-per-row backward: mu rows dense, mu / grad z / d mu 16-byte aligned (flat 128-bit tile moves)
 };
 
 // kappa of a row: the stored value, or softplus(raw) + 1 when the call passes raw head outputs (VMF_FLAG_SOFTPLUS_KAPPA)
@@ -842,6 +843,198 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
   }
 }
 
+// Backward for the narrow widths of vmf_rsample_rowlane_kernel (fp32, counter noise): ONE lane owns a row, as there.  The
+// tile's mu, then its grad z, move from HBM as flat arrays of 16-byte units through one wave-private LDS slab into the
+// lane's registers; d mu goes back through the same slab.  No cross-lane sums; the lane-group kernel above gives these
+// rows scalar, guarded element accesses and idle lanes (m = 10: 47 % of the HBM rate).  Same arithmetic as the kernel
+// above, sums taken in element order.
+template <int M>
+__global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_rowlane_kernel(GenParams<float> p) {
+  using T = float;
+  constexpr int RL_TILE = rl_tile(M);
+  constexpr int UNITS = RL_TILE * M / 4;
+  constexpr int UPL = (UNITS + 63) / 64;
+  constexpr int CHUNKS = (M + 3) / 4;
+  __shared__ __align__(16) T s_rows[WAVES][RL_TILE * M];
+  const PhiloxKey key = philox_resolve(p.ka);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* const srow = s_rows[wave];
+  const int64_t tile0 = ((int64_t)blockIdx.x * WAVES + wave) * RL_TILE;  // wave-uniform
+  const int64_t left = p.n - tile0;
+  if (left <= 0) return;  // the kernel has no workgroup barrier
+  const int ntile = left < RL_TILE ? (int)left : RL_TILE;
+  const bool full = p.dense16 && ntile == RL_TILE;
+  const T* const mu_t = p.mu + tile0 * p.mu_stride;
+  const T* const gz_t = p.gz + tile0 * M;
+  T* const dmu_t = p.dmu + tile0 * M;
+  const uint64_t grow0 = p.row0 + (uint64_t)tile0;
+  u32x4 st_mu[UPL], st_g[UPL];
+  if (full) {
+#pragma unroll
+    for (int s = 0; s < UPL; ++s) {
+      const int q = lane + 64 * s;
+      if (UNITS % 64 == 0 || q < UNITS) {
+        st_mu[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(mu_t) + q);
+        st_g[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(gz_t) + q);
+      }
+    }
+  }
+  // a lane's rows: lane, lane + 64, ... (RL_TILE / 64 of them), held in registers across the two slab passes
+  constexpr int SUBS = RL_TILE / 64;
+  T mu[SUBS][M], G[SUBS][M];
+  auto park = [&](const u32x4 (&st)[UPL], const T* src, int64_t stride) {
+    if (full) {
+#pragma unroll
+      for (int s = 0; s < UPL; ++s) {
+        const int q = lane + 64 * s;
+        if (UNITS % 64 == 0 || q < UNITS) reinterpret_cast<u32x4*>(srow)[q] = st[s];
+      }
+    } else {
+      for (int e = lane; e < ntile * M; e += 64) srow[e] = src[(e / M) * stride + e % M];
+    }
+    wave_lds_sync();
+  };
+  auto take = [&](T (&dst)[SUBS][M]) {
+#pragma unroll
+    for (int sub = 0; sub < SUBS; ++sub) {
+      const int r = sub * 64 + lane;
+      if (r < ntile) {
+        if (M % 2 == 0) {
+#pragma unroll
+          for (int e = 0; e < M; e += 2) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(srow + r * M + e);
+            dst[sub][e] = v.x; dst[sub][e + 1] = v.y;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < M; ++e) dst[sub][e] = srow[r * M + e];
+        }
+      }
+    }
+    wave_lds_sync();
+  };
+  park(st_mu, mu_t, p.mu_stride);
+  take(mu);
+  park(st_g, gz_t, M);
+  take(G);
+  const bool sp = p.softplus != 0;
+#pragma unroll
+  for (int sub = 0; sub < SUBS; ++sub) {
+    const int r = sub * 64 + lane;
+    if (r < ntile) {
+      const int64_t row = tile0 + r;
+      T g[M];
+#pragma unroll
+      for (int c = 0; c < CHUNKS; ++c) {
+        const U4 rr = philox4x32_10(grow0 + (uint64_t)r, SLOT_GAUSS + (uint32_t)c, key);
+        T n0, n1;
+        box_muller<T>(u01<T>(rr.x), u01<T>(rr.y), &n0, &n1);
+        if (4 * c < M) g[4 * c] = n0;
+        if (4 * c + 1 < M) g[4 * c + 1] = n1;
+        if (4 * c + 2 < M) {
+          box_muller<T>(u01<T>(rr.z), u01<T>(rr.w), &n0, &n1);
+          g[4 * c + 2] = n0;
+          if (4 * c + 3 < M) g[4 * c + 3] = n1;
+        }
+      }
+      g[0] = (T)0;
+      T gg = 0, dd = 0, gm = 0, Gd = 0, Gg = 0;
+#pragma unroll
+      for (int e = 1; e < M; ++e) {
+        gg += g[e] * g[e];
+        dd += mu[sub][e] * mu[sub][e];
+        gm += g[e] * mu[sub][e];
+        Gd += G[sub][e] * mu[sub][e];
+        Gg += G[sub][e] * g[e];
+      }
+      T mu0 = mu[sub][0];
+      const T G0 = G[sub][0];
+      const T inv = p.normalize ? F<T>::rsqrt(dd + mu0 * mu0) : (T)1;
+      mu0 *= inv;
+      gm *= inv;
+      Gd = G0 * ((T)1 - mu0) - Gd * inv;
+      dd = ((T)1 - mu0) * ((T)1 - mu0) + dd * (inv * inv);
+      const T w = p.w_in[row];
+      const T omw = p.omw_in ? p.omw_in[row] : (T)1 - w;
+      T ksig;
+      const T kap = kappa_of<T>(p.kappa[row * p.kappa_stride], sp, &ksig);
+      T c2 = omw * ((T)1 + w);
+      const bool inside = c2 >= (T)1e-10;
+      c2 = inside ? c2 : (T)1e-10;
+      const T sq = F<T>::sqrt(c2), gn = F<T>::sqrt(gg);
+      const T rgn = F<T>::rcp(gn);
+      const T f = sq * rgn;
+      const T d0 = (T)1 - mu0;
+      const T zd = w * d0 - f * gm;
+      const bool refl = dd > (T)1e-30;
+      const T inv_dd = refl ? F<T>::rcp(dd) : (T)0;
+      T out[M];
+      T dot = 0;
+#pragma unroll
+      for (int e = 0; e < M; ++e) {
+        const T zp = e == 0 ? w : f * g[e];
+        const T mh = mu[sub][e] * inv;
+        const T de = e == 0 ? d0 : -mh;
+        out[e] = (T)2 * (zp * Gd + zd * G[sub][e] - (T)2 * zd * Gd * de * inv_dd) * inv_dd;
+        dot += out[e] * mh;
+      }
+      if (p.normalize) {
+#pragma unroll
+        for (int e = 0; e < M; ++e) out[e] = (out[e] - mu[sub][e] * inv * dot) * inv;
+      }
+      if (M % 2 == 0) {
+#pragma unroll
+        for (int e = 0; e < M; e += 2) {
+          f32x2 v;
+          v.x = out[e]; v.y = out[e + 1];
+          *reinterpret_cast<f32x2*>(srow + r * M + e) = v;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < M; ++e) srow[r * M + e] = out[e];
+      }
+      const T Gp0 = G0 - (T)2 * Gd * inv_dd * d0;
+      const T S = Gg + (T)2 * Gd * gm * inv_dd;
+      const T dw = Gp0 + (inside ? S * rgn * (-w * F<T>::rcp(sq)) : (T)0);
+      const T m1 = (T)(M - 1);
+      const T c = F<T>::sqrt((T)4 * kap * kap + m1 * m1);
+      const T b = m1 * F<T>::rcp((T)2 * kap + c);
+      const T e_ = omw * F<T>::rcp(((T)1 + b) - w * ((T)1 - b));
+      const T den = (T)1 - ((T)1 - b) * e_;
+      const T dw_db = (T)-2 * e_ * ((T)1 - e_) * F<T>::rcp(den * den);
+      T dk = dw * dw_db * ((T)-2 * b * F<T>::rcp(c));
+      if (p.gkappa) dk += p.gkappa[row];
+      p.dkappa[row] = dk * ksig;
+    }
+  }
+  wave_lds_sync();
+  if (full) {
+#pragma unroll
+    for (int s = 0; s < UPL; ++s) {
+      const int q = lane + 64 * s;
+      if (UNITS % 64 == 0 || q < UNITS) {
+        f32x4 v;
+        const u32x4 raw = reinterpret_cast<const u32x4*>(srow)[q];
+        __builtin_memcpy(&v, &raw, 16);
+        store_nt(v, dmu_t + 4 * q);
+      }
+    }
+  } else {
+    for (int e = lane; e < ntile * M; e += 64) dmu_t[e] = srow[e];
+  }
+}
+
+static void launch_bwd_rowlane(const GenParams<float>& p, hipStream_t s) {
+  const int64_t tiles = (p.n + rl_tile(p.m) - 1) / rl_tile(p.m);
+  const dim3 grid((unsigned)((tiles + WAVES - 1) / WAVES)), block(WAVES * 64);
+  switch (p.m) {
+#define VMF_RL(MM) case MM: hipLaunchKernelGGL((vmf_rsample_bwd_rowlane_kernel<MM>), grid, block, 0, s, p); break
+    VMF_RL(3); VMF_RL(5); VMF_RL(6); VMF_RL(7); VMF_RL(9); VMF_RL(10); VMF_RL(11); VMF_RL(13); VMF_RL(14); VMF_RL(15);
+#undef VMF_RL
+    default: break;
+  }
+}
+
 // log C_m(kappa_i) for every row: pre-pass of the fused log_prob (keeps the Bessel code, and its registers,
 // out of the streaming kernel)
 template <typename T>
@@ -1010,6 +1203,16 @@ static int rsample_bwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   int64_t gb = (waves + WAVES - 1) / WAVES;
   VMF_REQUIRE(gb <= 0x7fffffff, VMF_ERR_UNSUPPORTED, "n=%lld rows need more than 2^31 workgroups", (long long)n);
   const int grid = (int)(gb < 1 ? 1 : gb);
+  if constexpr (sizeof(T) == 4) {
+    // narrow rows of a width that is not a multiple of four, regenerated noise: one lane per row whatever the layout
+    if (rowlane_ok(m) && !gauss) {
+      VMF_REQUIRE((n + rl_tile(m) - 1) / rl_tile(m) / WAVES < 0x7fffffff, VMF_ERR_UNSUPPORTED,
+                  "n=%lld rows need more than 2^31 workgroups", (long long)n);
+      p.dense16 = mu_stride == m && aligned16(mu) && aligned16(gz) && aligned16(dmu);
+      launch_bwd_rowlane(p, s);
+      return VMF_OK;
+    }
+  }
   if (vec) launch_bwd<T, true>(p, grid, s);
   else launch_bwd<T, false>(p, grid, s);
   return VMF_OK;

@@ -283,7 +283,8 @@ def test_vmf3_torch_rng_mode_replays_reference_draw_order(monkeypatch):
 
 @pytest.mark.parametrize("shape", ["rows_small", "rows_tiles", "outer"])
 def test_vmf3_philox_mode_vs_oracle(monkeypatch, oracle, shape):
-    """in-kernel noise: u_i from Philox(index i, slot 0), eps row j from Philox(index j, slot 1), whichever kernel the
+    """in-kernel noise: Philox(index, slot 0) = (x, y, z, w) serves u_i (upper 23 bits of x of index i) and the eps row j
+    (Box-Muller(y, z), Box-Muller(w, t), t = the lower 9 bits of x, y, z side by side, of index j), whichever kernel the
     shape takes (scalar rows, staged 256-row tiles, the outer product) -- forward and the backward's regenerated noise"""
     monkeypatch.setenv("VMF_RNG", "philox")
     lib = oracle.lib()
@@ -303,8 +304,9 @@ def test_vmf3_philox_mode_vs_oracle(monkeypatch, oracle, shape):
         lib.orc_philox4x32_10(C.c_uint64(i), C.c_uint32(0), C.c_uint64(0xABCDEF0123), C.c_uint64(5), out)
         u[i] = lib.orc_u01(out[0])
     for i in range(nj):
-        lib.orc_philox4x32_10(C.c_uint64(i), C.c_uint32(1), C.c_uint64(0xABCDEF0123), C.c_uint64(5), out)
-        uu = [lib.orc_u01(out[j]) for j in range(4)]
+        lib.orc_philox4x32_10(C.c_uint64(i), C.c_uint32(0), C.c_uint64(0xABCDEF0123), C.c_uint64(5), out)
+        fifth = ((out[0] & 0x1FF) << 23) | ((out[1] & 0x1FF) << 14) | ((out[2] & 0x1FF) << 5)
+        uu = [lib.orc_u01(C.c_uint32(x)) for x in (out[1], out[2], out[3], fifth)]
         r0, r1 = np.sqrt(-2 * np.log(uu[0])), np.sqrt(-2 * np.log(uu[2]))
         eps[i] = [r0 * np.cos(2 * np.pi * uu[1]), r0 * np.sin(2 * np.pi * uu[1]), r1 * np.cos(2 * np.pi * uu[3])]
     u = u.reshape(scale.shape)
@@ -1720,3 +1722,27 @@ def test_error_conventions():
     assert rc == -1 and b"null" in _lib.lib().vmf_last_error_string()
     rc = _lib.lib().vmf_ive_fwd(0.5, _lib.ptr(loc), _lib.ptr(loc), 4, 7, None)
     assert rc == -2
+
+
+def test_empty_inputs_behave_like_torch_ops():
+    """zero rows / zero samples: the reference's torch expressions return empty tensors (and `.mean()` of nothing is
+    NaN); nothing is launched on an empty grid, gradients are empty too"""
+    z = VonMisesFisher3D(torch.zeros(0, 3, device=DEV), torch.zeros(0, device=DEV), validate_args=False).rsample()
+    assert z.shape == (0, 3)
+    z = VonMisesFisher3D(torch.zeros(0, 3, device=DEV), torch.zeros(0, 1, device=DEV), validate_args=False).rsample()
+    assert z.shape == (0, 0, 3)
+    q = VonMisesFisher3D(torch.randn(4, 3, device=DEV), torch.ones(4, device=DEV), validate_args=False)
+    assert q.rsample(torch.Size([0])).shape == (0, 4, 3)
+    assert VonMisesFisher(torch.zeros(0, 10, device=DEV), torch.zeros(0, device=DEV), validate_args=False).rsample().shape \
+        == (0, 10)
+    assert ive(0.5, torch.zeros(0, device=DEV)).shape == (0,)
+    assert klmod.kl_per_sample(torch.zeros(0, device=DEV), "spherical").shape == (0,)
+    assert bool(torch.isnan(klmod.kl_mean(torch.zeros(0, device=DEV), "spherical")))
+    assert SphericalUniform(3, device=DEV).sample(torch.Size([0])).shape == (0, 3)
+    l = torch.zeros(0, 3, device=DEV, requires_grad=True)
+    k = torch.zeros(0, device=DEV, requires_grad=True)
+    VonMisesFisher3D(l, k, validate_args=False).rsample().sum().backward()
+    assert l.grad.shape == (0, 3) and k.grad.shape == (0,)
+    x = torch.zeros(0, device=DEV, requires_grad=True)
+    ive(1.5, x).sum().backward()
+    assert x.grad.shape == (0,)
