@@ -128,6 +128,43 @@ def require_hip(*tensors):
     return dev
 
 
+class _Noop:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOOP = _Noop()
+
+
+def on_device(dev):
+    """Context that makes `dev` the current device for a launch (the library launches on the current device).  When
+    it already is -- the usual case -- nothing is switched: torch.cuda.device() costs several microseconds per call,
+    a visible share of a launch at the reference's batch sizes."""
+    if dev.index is None or torch.cuda.current_device() == dev.index:
+        return _NOOP
+    return torch.cuda.device(dev)
+
+
+_workspaces = {}
+
+
+def workspace(dev, n_doubles):
+    """Scratch of `n_doubles` float64 for a reduction's block partials, one per (device, stream, size), kept for the
+    life of the process: launches on one stream are ordered, so back-to-back calls may share it, and a train step
+    captured into a HIP graph then contains no allocation for it (the warm-up steps before the capture created it).
+    A first call made while the stream is capturing gets a buffer of its own from the capture's pool instead."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, n_doubles)
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = torch.empty(n_doubles, device=dev, dtype=torch.float64)
+        if not torch.cuda.is_current_stream_capturing():
+            _workspaces[key] = ws
+    return ws
+
+
 def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 

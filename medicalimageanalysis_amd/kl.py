@@ -19,7 +19,7 @@ class _KLPerSample(torch.autograd.Function):
         dev = _lib.require_hip(kappa)
         kc = kappa.detach().contiguous()
         out = torch.empty_like(kc)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf_kl_fwd(_lib.ptr(kc), _lib.ptr(out), None, None, 1.0, kc.numel(), variant,
                                        _lib.dtype_code(kc), _lib.stream_ptr(dev))
         _lib.check(rc, "vmf_kl_fwd")
@@ -33,7 +33,7 @@ class _KLPerSample(torch.autograd.Function):
         dev = kc.device
         g = gout.to(kc.dtype).expand(kc.shape).contiguous()
         dk = torch.empty_like(kc)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf_kl_bwd(_lib.ptr(kc), _lib.ptr(g), 1, 1.0, _lib.ptr(dk), kc.numel(), ctx.variant,
                                        _lib.dtype_code(kc), _lib.stream_ptr(dev))
         _lib.check(rc, "vmf_kl_bwd")
@@ -47,9 +47,9 @@ class _KLReduced(torch.autograd.Function):
     def forward(ctx, kappa, variant, alpha):
         dev = _lib.require_hip(kappa)
         kc = kappa.detach().contiguous()
-        ws = torch.empty(_lib.KL_WORKSPACE_DOUBLES, device=dev, dtype=torch.float64)
+        ws = _lib.workspace(dev, _lib.KL_WORKSPACE_DOUBLES)
         acc = torch.empty(1, device=dev, dtype=torch.float64)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf_kl_fwd(_lib.ptr(kc), None, _lib.ptr(acc), _lib.ptr(ws), float(alpha), kc.numel(),
                                        variant, _lib.dtype_code(kc), _lib.stream_ptr(dev))
         _lib.check(rc, "vmf_kl_fwd")
@@ -63,7 +63,7 @@ class _KLReduced(torch.autograd.Function):
         dev = kc.device
         g = gout.to(kc.dtype).reshape(1).contiguous()
         dk = torch.empty_like(kc)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf_kl_bwd(_lib.ptr(kc), _lib.ptr(g), 0, ctx.alpha, _lib.ptr(dk), kc.numel(),
                                        ctx.variant, _lib.dtype_code(kc), _lib.stream_ptr(dev))
         _lib.check(rc, "vmf_kl_bwd")

@@ -33,8 +33,8 @@ class _Elbo(torch.autograd.Function):
             xc, hc = xb.contiguous(), hb.contiguous()
         kc = kappa.detach().contiguous()
         loss = torch.empty((), device=dev, dtype=hc.dtype)
-        ws = torch.empty(_lib.ELBO_WORKSPACE_DOUBLES, device=dev, dtype=torch.float64)
-        with torch.cuda.device(dev):
+        ws = _lib.workspace(dev, _lib.ELBO_WORKSPACE_DOUBLES)
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf_elbo_fwd(_lib.ptr(xc), _lib.ptr(hc), _lib.ptr(kc), _lib.ptr(loss), None, _lib.ptr(ws),
                                          a_rec, a_kl, xc.numel(), hc.numel(), kc.numel(), variant,
                                          _lib.dtype_code(hc), _lib.stream_ptr(dev))
@@ -52,7 +52,7 @@ class _Elbo(torch.autograd.Function):
         g = _scalar_grad(gout, hc)
         dh = torch.empty_like(hc) if (need_h or need_x) else None
         dk = torch.empty_like(kc) if need_k else None
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf_elbo_bwd(_lib.ptr(xc), _lib.ptr(hc), _lib.ptr(kc), _lib.ptr(g), _lib.ptr(dh),
                                          _lib.ptr(dk), a_rec, a_kl, xc.numel(), hc.numel(), kc.numel(), variant,
                                          _lib.dtype_code(hc), _lib.stream_ptr(dev))
@@ -101,7 +101,7 @@ class _BuildTorus(torch.autograd.Function):
         zdim = tc.shape[-1]
         n = tc.numel() // zdim
         out = torch.empty(tc.shape[:-1] + (3,), device=dev, dtype=tc.dtype)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf_build_torus_fwd(_lib.ptr(tc), _lib.ptr(pc), _lib.ptr(out), n, zdim, R, r,
                                                 _lib.dtype_code(tc), _lib.stream_ptr(dev))
         _lib.check(rc, "vmf_build_torus_fwd")
@@ -117,7 +117,7 @@ class _BuildTorus(torch.autograd.Function):
         g = gout.to(tc.dtype).contiguous()
         gt, gp = torch.empty_like(tc), torch.empty_like(pc)
         zdim = tc.shape[-1]
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf_build_torus_bwd(_lib.ptr(tc), _lib.ptr(pc), _lib.ptr(g), _lib.ptr(gt), _lib.ptr(gp),
                                                 tc.numel() // zdim, zdim, R, r, _lib.dtype_code(tc),
                                                 _lib.stream_ptr(dev))
@@ -147,8 +147,8 @@ class _LatentLoss(torch.autograd.Function):
         zdim = zc.shape[-1]
         n = zc.numel() // zdim
         out = torch.empty((), device=dev, dtype=zc.dtype)
-        ws = torch.empty(_lib.KL_WORKSPACE_DOUBLES, device=dev, dtype=torch.float64)
-        with torch.cuda.device(dev):
+        ws = _lib.workspace(dev, _lib.KL_WORKSPACE_DOUBLES)
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf_latent_loss_fwd(_lib.ptr(zc), _lib.ptr(lc), None, _lib.ptr(out), _lib.ptr(ws), n, zdim,
                                                 lc.shape[0], lc.shape[1], variant, R, r, _lib.dtype_code(zc),
                                                 _lib.stream_ptr(dev))
@@ -165,7 +165,7 @@ class _LatentLoss(torch.autograd.Function):
         g = _scalar_grad(gout, zc)
         dz = torch.empty_like(zc)
         zdim = zc.shape[-1]
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf_latent_loss_bwd(_lib.ptr(zc), _lib.ptr(lc), _lib.ptr(g), _lib.ptr(dz),
                                                 zc.numel() // zdim, zdim, lc.shape[0], lc.shape[1], variant, R, r,
                                                 _lib.dtype_code(zc), _lib.stream_ptr(dev))

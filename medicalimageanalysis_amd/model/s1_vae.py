@@ -18,7 +18,7 @@ class _S1ProjNormal(torch.autograd.Function):
         kc = kappa.detach().to(mc.dtype).reshape(-1).contiguous()
         nc = None if noise is None else noise.contiguous()
         z = torch.empty_like(mc)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf_s1_projnormal_fwd(_lib.ptr(mc), _lib.ptr(kc), _lib.ptr(nc), _lib.ptr(z), n, dim, 0,
                                                   seed, offset, _lib.ptr(offset_dev), _lib.dtype_code(mc),
                                                   _lib.stream_ptr(dev))
@@ -36,7 +36,7 @@ class _S1ProjNormal(torch.autograd.Function):
         dev = mc.device
         g = gz.to(mc.dtype).contiguous()
         dm, dk = torch.empty_like(mc), torch.empty_like(kc)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf_s1_projnormal_bwd(_lib.ptr(mc), _lib.ptr(kc), _lib.ptr(nc), _lib.ptr(g), _lib.ptr(dm),
                                                   _lib.ptr(dk), n, dim, 0, seed, offset, _lib.ptr(ctx.offset_dev),
                                                   _lib.dtype_code(mc),

@@ -12,7 +12,7 @@ def _launch_unary(fn_name, v, z):
     dev = _lib.require_hip(z)
     zc = z.detach().contiguous()
     out = torch.empty_like(zc)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = getattr(_lib.lib(), fn_name)(float(v), _lib.ptr(zc), _lib.ptr(out), zc.numel(), _lib.dtype_code(zc),
                                           _lib.stream_ptr(dev))
     _lib.check(rc, fn_name)
@@ -37,7 +37,7 @@ class IveFunction(torch.autograd.Function):
         zc = z.detach().contiguous()
         go = grad_output.to(zc.dtype).expand_as(zc).contiguous()
         gz = torch.empty_like(zc)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf_ive_bwd(float(v), _lib.ptr(zc), _lib.ptr(go), _lib.ptr(gz), zc.numel(),
                                         _lib.dtype_code(zc), _lib.stream_ptr(dev))
         _lib.check(rc, "vmf_ive_bwd")

@@ -18,7 +18,7 @@ def _sphere_sample(shape_rows, dim, device, dtype, gauss=None, row0=0, generator
     seed, offset, offset_dev = (0, 0, None)
     if gauss is None:
         seed, offset, offset_dev = (generator or rng.default_generator).ticket(dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.lib().vmf_sphere_uniform_sample(_lib.ptr(gauss), _lib.ptr(out), n, dim, row0, seed, offset,
                                                   _lib.ptr(offset_dev),
                                                   _lib.dtype_code(out), _lib.stream_ptr(dev))

@@ -7,6 +7,7 @@ checks and autograd glue.
 """
 import math  # noqa: F401  (re-exported: the reference's model files reach `math` through `from sampler.von_mises_fisher import *`)
 
+import functools
 import os
 
 import torch
@@ -41,8 +42,13 @@ def vmf3_broadcast_plan(loc_shape, scale_shape, sample_shape=()):
     """Shapes/strides of `w.unsqueeze(-1) * loc + factor * v` (sampler/von_mises_fisher.py:82-84).
 
     w has shape sample_shape + scale.shape, loc/eps/v have shape sample_shape + loc.shape; the result is their
-    broadcast -- (B, 3) for scale (B,), and the (B, B, 3) outer product for the (B, 1) scale the VAEs pass."""
-    loc_shape, scale_shape, sample_shape = tuple(loc_shape), tuple(scale_shape), tuple(sample_shape)
+    broadcast -- (B, 3) for scale (B,), and the (B, B, 3) outer product for the (B, 1) scale the VAEs pass.
+    Plans are cached per shape triple (a train loop asks for the same one every step); treat the dict as read-only."""
+    return _plan_cached(tuple(loc_shape), tuple(scale_shape), tuple(sample_shape))
+
+
+@functools.lru_cache(maxsize=512)
+def _plan_cached(loc_shape, scale_shape, sample_shape):
     lrows = loc_shape[:-1]
     w_shape = sample_shape + scale_shape
     e_shape = sample_shape + lrows
@@ -51,11 +57,14 @@ def vmf3_broadcast_plan(loc_shape, scale_shape, sample_shape=()):
     if len(odims) > _MAX_DIMS:
         raise RuntimeError(f"rsample result has {len(odims)} batch dims; at most {_MAX_DIMS} are supported")
     pad = lambda s: s if len(o_shape) else [0]  # noqa: E731
-    return {
+    plan = {
         "o_shape": o_shape, "w_shape": w_shape, "e_shape": e_shape, "odims": list(odims),
         "w_str": pad(_bstrides(w_shape, o_shape)), "k_str": pad(_bstrides(scale_shape, o_shape)),
         "l_str": pad(_bstrides(lrows, o_shape)), "e_str": pad(_bstrides(e_shape, o_shape)),
     }
+    # the ctypes arrays the entry points take, built once
+    plan["c_args"] = (len(plan["odims"]),) + tuple(_lib.i64_array(plan[k]) for k in ("odims", "w_str", "k_str", "l_str", "e_str"))
+    return plan
 
 
 def _numel(shape):
@@ -77,10 +86,7 @@ def _plan_kind(plan):
     """(kind, n_i, n_j) of a broadcast plan as the library classifies it (vmf3_broadcast_kind; host only)"""
     if "kind" not in plan:
         ni, nj = _lib.C.c_int64(0), _lib.C.c_int64(0)
-        kind = _lib.lib().vmf3_broadcast_kind(
-            len(plan["odims"]), _lib.i64_array(plan["odims"]), _lib.i64_array(plan["w_str"]),
-            _lib.i64_array(plan["k_str"]), _lib.i64_array(plan["l_str"]), _lib.i64_array(plan["e_str"]),
-            _lib.C.byref(ni), _lib.C.byref(nj))
+        kind = _lib.lib().vmf3_broadcast_kind(*plan["c_args"], _lib.C.byref(ni), _lib.C.byref(nj))
         if kind < 0:
             _lib.check(kind, "vmf3_broadcast_kind")
         plan["kind"] = (kind, ni.value, nj.value)
@@ -102,12 +108,10 @@ class _VMF3RSample(torch.autograd.Function):
         kappa = torch.empty_like(scalec) if softplus else None
         flags = _lib.FLAG_SOFTPLUS_KAPPA if softplus else 0
         if z.numel():
-            with torch.cuda.device(dev):
+            with _lib.on_device(dev):
                 rc = _lib.lib().vmf3_rsample_fwd(
                     _lib.ptr(locc), _lib.ptr(scalec), _lib.ptr(uc), _lib.ptr(epsc), _lib.ptr(z), None, _lib.ptr(kappa),
-                    len(plan["odims"]), _lib.i64_array(plan["odims"]), _lib.i64_array(plan["w_str"]),
-                    _lib.i64_array(plan["k_str"]), _lib.i64_array(plan["l_str"]), _lib.i64_array(plan["e_str"]),
-                    flags, _lib.dtype_code(loc), seed, offset, _lib.ptr(offset_dev), _lib.stream_ptr(dev))
+                    *plan["c_args"], flags, _lib.dtype_code(loc), seed, offset, _lib.ptr(offset_dev), _lib.stream_ptr(dev))
             _lib.check(rc, "vmf3_rsample_fwd")
         elif softplus and kappa.numel():
             kappa = torch.nn.functional.softplus(scalec) + 1  # nothing to sample: no kernel ran
@@ -134,8 +138,10 @@ class _VMF3RSample(torch.autograd.Function):
             nbytes = _lib.C.c_int64(0)
             _lib.check(lib.vmf3_rsample_bwd_outer_workspace(n_i, n_j, _lib.dtype_code(locc), _lib.C.byref(nbytes)),
                        "vmf3_rsample_bwd_outer_workspace")
-            ws = torch.empty((nbytes.value + 7) // 8, device=dev, dtype=torch.float64)
-            with torch.cuda.device(dev):
+            nd = (nbytes.value + 7) // 8
+            # batch-sized shapes share a cached scratch (no allocation inside a captured step); large ones come and go
+            ws = _lib.workspace(dev, nd) if nd <= (1 << 17) else torch.empty(nd, device=dev, dtype=torch.float64)
+            with _lib.on_device(dev):
                 rc = lib.vmf3_rsample_bwd_outer(_lib.ptr(locc), _lib.ptr(scalec), _lib.ptr(uc), _lib.ptr(epsc),
                                                 _lib.ptr(gzc), _lib.ptr(gkc), _lib.ptr(dloc), _lib.ptr(dscale), n_i, n_j,
                                                 _lib.ptr(ws), ws.numel() * 8, *common)
@@ -153,13 +159,11 @@ class _VMF3RSample(torch.autograd.Function):
             dloc, dscale = torch.empty_like(locc), torch.empty_like(scalec)
         in_kernel_gk = gkc is not None and not shared and kind == _lib.KIND_ROWS
         if dloc.numel() or dscale.numel():
-            with torch.cuda.device(dev):
+            with _lib.on_device(dev):
                 rc = lib.vmf3_rsample_bwd(
                     _lib.ptr(locc), _lib.ptr(scalec), _lib.ptr(uc), _lib.ptr(epsc), _lib.ptr(gzc),
                     _lib.ptr(gkc) if in_kernel_gk else None, _lib.ptr(dloc), _lib.ptr(dscale),
-                    n_out if per_row else n_loc, n_out if per_row else n_scale, len(odims),
-                    _lib.i64_array(odims), _lib.i64_array(plan["w_str"]), _lib.i64_array(plan["k_str"]),
-                    _lib.i64_array(plan["l_str"]), _lib.i64_array(plan["e_str"]), *common)
+                    n_out if per_row else n_loc, n_out if per_row else n_scale, *plan["c_args"], *common)
             _lib.check(rc, "vmf3_rsample_bwd")
         if per_row:
             ldims = [d for d, (n, st) in enumerate(zip(odims, plan["l_str"])) if st == 0 and n > 1]
@@ -202,7 +206,7 @@ class _VMF3SampleW(torch.autograd.Function):
         sc = scale.detach().contiguous()
         uc = None if u is None else u.to(sc.dtype).contiguous()
         w = torch.empty(w_shape, device=dev, dtype=sc.dtype)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf3_sample_w_fwd(_lib.ptr(sc), _lib.ptr(uc), _lib.ptr(w), w.numel(), sc.numel(),
                                               _lib.dtype_code(sc), seed, offset, _lib.ptr(offset_dev),
                                               _lib.stream_ptr(dev))
@@ -218,7 +222,7 @@ class _VMF3SampleW(torch.autograd.Function):
         dev = sc.device
         g = gw.to(sc.dtype).contiguous()
         rows = torch.empty_like(g)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf3_sample_w_bwd(_lib.ptr(sc), _lib.ptr(uc), _lib.ptr(g), _lib.ptr(rows), g.numel(),
                                               sc.numel(), _lib.dtype_code(sc), seed, offset, _lib.ptr(offset_dev),
                                               _lib.stream_ptr(dev))
@@ -321,7 +325,7 @@ class VonMisesFisher3D(Distribution):
         scale = self.scale.detach().to(loc.dtype).expand(loc.shape[:-1]).contiguous()
         dev = _lib.require_hip(loc, scale)
         out = torch.empty_like(loc)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf3_mean(_lib.ptr(loc), _lib.ptr(scale), _lib.ptr(out), scale.numel(),
                                       _lib.dtype_code(loc), _lib.stream_ptr(dev))
         _lib.check(rc, "vmf3_mean")
@@ -334,7 +338,7 @@ class _VMF3LogProbRef(torch.autograd.Function):
         dev = _lib.require_hip(loc, scale, x)
         locc, sc, xc = loc.detach().contiguous(), scale.detach().contiguous(), x.detach().contiguous()
         logp = torch.empty_like(sc)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf3_log_prob_ref(_lib.ptr(locc), _lib.ptr(sc), _lib.ptr(xc), _lib.ptr(logp), None, sc.numel(),
                                               _lib.dtype_code(locc), _lib.stream_ptr(dev))
         _lib.check(rc, "vmf3_log_prob_ref")
@@ -347,7 +351,7 @@ class _VMF3LogProbRef(torch.autograd.Function):
         dev = locc.device
         g = gl.to(locc.dtype).contiguous()
         dloc, dscale, dx = torch.empty_like(locc), torch.empty_like(sc), torch.empty_like(xc)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf3_log_prob_ref_bwd(_lib.ptr(locc), _lib.ptr(sc), _lib.ptr(xc), _lib.ptr(g), _lib.ptr(dloc),
                                                   _lib.ptr(dscale), _lib.ptr(dx), sc.numel(), _lib.dtype_code(locc),
                                                   _lib.stream_ptr(dev))
@@ -386,7 +390,7 @@ class _VMF3LogNormRef(torch.autograd.Function):
         dev = _lib.require_hip(scale)
         sc = scale.detach().contiguous()
         lognorm = torch.empty_like(sc)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf3_log_prob_ref(None, _lib.ptr(sc), None, None, _lib.ptr(lognorm), sc.numel(),
                                               _lib.dtype_code(sc), _lib.stream_ptr(dev))
         _lib.check(rc, "vmf3_log_prob_ref")
@@ -402,7 +406,7 @@ class _VMF3LogNormRef(torch.autograd.Function):
         x = torch.zeros(sc.shape + (3,), device=dev, dtype=sc.dtype)
         loc = torch.ones_like(x)
         dscale = torch.empty_like(sc)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf3_log_prob_ref_bwd(_lib.ptr(loc), _lib.ptr(sc), _lib.ptr(x), _lib.ptr(gl), None,
                                                   _lib.ptr(dscale), None, sc.numel(), _lib.dtype_code(sc),
                                                   _lib.stream_ptr(dev))
@@ -427,7 +431,7 @@ class _VMFRSample(torch.autograd.Function):
         logp = torch.empty((n,), device=dev, dtype=mu.dtype) if want_logp else None
         soft = bool(flags & _lib.FLAG_SOFTPLUS_KAPPA)
         kout = torch.empty((n,), device=dev, dtype=mu.dtype) if soft else None
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf_rsample_fwd(_lib.ptr(muc), mu_stride, _lib.ptr(kc), kappa_stride, _lib.ptr(z),
                                             _lib.ptr(w), _lib.ptr(omw), None, _lib.ptr(logp), _lib.ptr(kout), n, m, None,
                                             None, 0, None, max_prop, row0, seed, offset, _lib.ptr(offset_dev), flags,
@@ -454,7 +458,7 @@ class _VMFRSample(torch.autograd.Function):
         gkc = None if gk is None else gk.to(muc.dtype).contiguous()
         dmu = torch.empty((n, m), device=dev, dtype=muc.dtype)
         dk = torch.empty((n,), device=dev, dtype=muc.dtype)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf_rsample_bwd(_lib.ptr(muc), mu_stride, _lib.ptr(kc), kappa_stride, _lib.ptr(w),
                                             _lib.ptr(omw), _lib.ptr(gzc), None, _lib.ptr(gkc), _lib.ptr(dmu), _lib.ptr(dk),
                                             n, m, row0, seed, offset, _lib.ptr(ctx.offset_dev), ctx.flags,
@@ -492,7 +496,7 @@ class _VMFLogProb(torch.autograd.Function):
         n, m = x.shape
         muc, kc, xc = mu.detach().contiguous(), kappa.detach().contiguous(), x.detach().contiguous()
         out = torch.empty((n,), device=dev, dtype=mu.dtype)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf_log_prob_fwd(_lib.ptr(muc), m, _lib.ptr(kc), 1, _lib.ptr(xc), _lib.ptr(out), n, m,
                                              _lib.dtype_code(muc), _lib.stream_ptr(dev))
         _lib.check(rc, "vmf_log_prob_fwd")
@@ -506,7 +510,7 @@ class _VMFLogProb(torch.autograd.Function):
         dev = muc.device
         glc = gl.to(muc.dtype).contiguous()
         dmu, dx, dk = torch.empty_like(muc), torch.empty_like(xc), torch.empty_like(kc)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf_log_prob_bwd(_lib.ptr(muc), m, _lib.ptr(kc), 1, _lib.ptr(xc), _lib.ptr(glc),
                                              _lib.ptr(dmu), _lib.ptr(dx), _lib.ptr(dk), n, m, _lib.dtype_code(muc),
                                              _lib.stream_ptr(dev))
@@ -522,7 +526,7 @@ class _VMFEntropy(torch.autograd.Function):
         dev = _lib.require_hip(kappa)
         kc = kappa.detach().contiguous()
         H, kl, dkl = torch.empty_like(kc), torch.empty_like(kc), torch.empty_like(kc)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().vmf_entropy_kl_fwd(_lib.ptr(kc), _lib.ptr(H), _lib.ptr(kl), _lib.ptr(dkl), kc.numel(), m,
                                                _lib.dtype_code(kc), _lib.stream_ptr(dev))
         _lib.check(rc, "vmf_entropy_kl_fwd")
