@@ -111,15 +111,21 @@ extern "C" int vmf_bessel_ratio_fwd(double v, const void* z, void* out, int64_t 
 // model/spherical_vae.py:153-182 with one pass; the `.mean()` of :134 is the fused two-stage sum.
 // VEC = 4: 128-bit loads / stores of four consecutive elements per lane (fp32, 16-byte aligned); the n % 4 tail is
 // taken by the first lanes with scalar accesses.
-// Each lane keeps KL_UNROLL 128-bit loads in flight (the element loop is a dependent chain otherwise: one 1 KiB
-// request per wave at a time leaves HBM idle).  The <= 1024 block partials of the workspace cap the grid at four
-// 256-thread blocks per CU, which must all be resident at once (85 VGPRs: five waves per SIMD fit, four are needed);
-// 512-thread blocks ran the grid in two rounds.
-#ifndef VMF_KL_UNROLL
-#define VMF_KL_UNROLL 4
+// Each lane keeps a few 128-bit loads in flight (the element loop is a dependent chain otherwise: one 1 KiB request per
+// wave at a time leaves HBM idle).  The <= 1024 block partials of the workspace cap the grid at four blocks per CU, so
+// the block size sets the occupancy: 512 threads = 8 waves per SIMD (every instantiation stays under 64 VGPRs), which
+// hides the quarter-rate transcendentals of the m = 3 forms far better than 256 threads x 4 loads did (2^27 elements:
+// torus 0.169 -> 0.118 ms, circular 0.167 -> 0.138, stable m=3 0.154 -> 0.126, spherical 0.188 -> 0.170; the
+// instruction-bound m = 2 fits 0.178 -> 0.165 / 0.170 -> 0.160 with three loads in flight, the others are best with two).
+#ifndef VMF_KL_BLOCK
+#define VMF_KL_BLOCK 512
 #endif
-constexpr int KL_UNROLL = VMF_KL_UNROLL;
-constexpr int KL_BLOCK = 256;
+constexpr int KL_BLOCK = VMF_KL_BLOCK;
+#ifdef VMF_KL_UNROLL
+constexpr int kl_unroll(int) { return VMF_KL_UNROLL; }
+#else
+constexpr int kl_unroll(int variant) { return (variant == VMF_KL_S1_I0I1 || variant == VMF_KL_STABLE_M2) ? 3 : 2; }
+#endif
 // VARIANT is a template argument: with the variant a run-time switch, every one of the 16 inlined per-element evaluations
 // of a trip carried all six forms (25 000 instructions in one kernel), and the kernels ran out of the instruction cache
 // rather than out of HBM.
@@ -130,10 +136,47 @@ __device__ __forceinline__ double sum4_to_double(const T (&v)[4]) {
   return ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
 }
 
+// Four consecutive elements.  The m = 3 variants in single precision have one straight-line form on the range an
+// encoder produces (kappa = softplus + 1 >= 1, below the point where the variant's own overflow behaviour starts): one
+// range check per four elements instead of the per-element region branches (spherical 27 -> 19 instructions per element);
+// a quad with any element outside the range -- or NaN -- takes the per-element form.  Same bits either way: both call
+// the same functions.
+template <typename T, bool BESSEL, int VARIANT>
+__device__ __forceinline__ void kl_eval_value4(const T (&k)[4], T (&o)[4], const KlBessel& kb) {
+#pragma unroll
+  for (int x = 0; x < 4; ++x) o[x] = kl_eval_value<T, BESSEL>(k[x], VARIANT, kb);
+}
+template <int VARIANT>
+__device__ __forceinline__ bool kl_quad_m3(const float (&k)[4], float (&o)[4]) {
+  constexpr float hi_limit = VARIANT == VMF_KL_SPHERICAL_PIECEWISE ? 1000.0f
+                             : (VARIANT == VMF_KL_STABLE_M3 ? 3.0e38f : 85.0f);
+  constexpr float eps = VARIANT == VMF_KL_SPHERICAL_PIECEWISE ? 1e-8f : (VARIANT == VMF_KL_CIRCULAR_EPS ? 1e-6f : 0.0f);
+  const float lo = fminf(fminf(k[0], k[1]), fminf(k[2], k[3])), hi = fmaxf(fmaxf(k[0], k[1]), fmaxf(k[2], k[3]));
+  // fminf / fmaxf drop a NaN operand: the sum test catches it
+  if (!(lo >= 1.0f && hi <= hi_limit) || (k[0] + k[1] + k[2] + k[3]) != (k[0] + k[1] + k[2] + k[3])) return false;
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+    o[x] = VARIANT == VMF_KL_STABLE_M3 ? kl_m3_stable_value(k[x]) : kl_m3_unified_value(k[x], eps);
+  return true;
+}
+#define VMF_KL_QUAD_M3(BESSEL, V)                                                                              \
+  template <>                                                                                                  \
+  __device__ __forceinline__ void kl_eval_value4<float, BESSEL, V>(const float (&k)[4], float (&o)[4],         \
+                                                                   const KlBessel& kb) {                       \
+    if (kl_quad_m3<V>(k, o)) return;                                                                           \
+    _Pragma("unroll") for (int x = 0; x < 4; ++x) o[x] = kl_eval_value<float, BESSEL>(k[x], V, kb);            \
+  }
+VMF_KL_QUAD_M3(false, VMF_KL_SPHERICAL_PIECEWISE)
+VMF_KL_QUAD_M3(false, VMF_KL_TORUS_RAW)
+VMF_KL_QUAD_M3(false, VMF_KL_CIRCULAR_EPS)
+VMF_KL_QUAD_M3(false, VMF_KL_STABLE_M3)
+#undef VMF_KL_QUAD_M3
+
 template <typename T, int VEC, bool BESSEL, int VARIANT>
 __global__ __launch_bounds__(KL_BLOCK) void kl_fwd_kernel(const T* __restrict__ kappa, T* __restrict__ out,
                                                           double* __restrict__ partial, int64_t n, KlBessel kb) {
   constexpr int variant = VARIANT;
+  constexpr int KL_UNROLL = kl_unroll(VARIANT);
   __shared__ double red[KL_BLOCK / 64];
   double acc = 0;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -154,10 +197,7 @@ __global__ __launch_bounds__(KL_BLOCK) void kl_fwd_kernel(const T* __restrict__ 
       const int64_t i = base + u * blockDim.x + threadIdx.x;
       if (i < nvec) {
         Vec4<T> o4;
-        o4.v[0] = kl_eval_value<T, BESSEL>(k4[u].v[0], variant, kb);
-        o4.v[1] = kl_eval_value<T, BESSEL>(k4[u].v[1], variant, kb);
-        o4.v[2] = kl_eval_value<T, BESSEL>(k4[u].v[2], variant, kb);
-        o4.v[3] = kl_eval_value<T, BESSEL>(k4[u].v[3], variant, kb);
+        kl_eval_value4<T, BESSEL, VARIANT>(k4[u].v, o4.v, kb);
         if (out) *reinterpret_cast<Vec4<T>*>(out + 4 * i) = o4;
         acc += sum4_to_double(o4.v);
       }

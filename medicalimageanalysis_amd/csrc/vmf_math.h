@@ -262,6 +262,21 @@ VMF_HD float cheb_sum_f32(const float (&c)[n], float t) {
 // q = (sinh k + eps) / k - 1, so nothing cancels (the textbook order loses all digits of the O(k^2) result to
 // log k - log sinh k and 1/k - k / sinh^2 k).  The derivative uses cosh^2 - sinh^2 = 1:
 // d/dk = 1/k + k (eps sinh k - 1) / (sinh k + eps)^2.
+// The straight-line m = 3 form in em = e^-k (derivation at its use below), value alone; k >= 1.  Three transcendental
+// instructions: log k - log D is taken as one logarithm.
+VMF_HD float kl_m3_unified_value(float k, float eps) {
+  const float em = fast_exp2(-1.44269504088896340736f * k), e2 = em * em;
+  const float D = 1.0f - e2 + 2.0f * eps * em;
+  const float rD = fast_rcp(D);
+  return fast_log(k * rD) + (0.69314718055994530942f - 1.0f) + 2.0f * k * (e2 - eps * em) * rD;
+}
+// the overflow-free m = 3 form for k >= 1: log k - log sinh k + k coth k - 1 with the two O(k) terms cancelled by hand,
+// k coth k - k = 2 k e2 / (1 - e2), e2 = e^-2k
+VMF_HD float kl_m3_stable_value(float k) {
+  const float e2 = fast_exp(-2.0f * k);
+  const float rom = fast_rcp(1.0f - e2);
+  return fast_log(k * rom) + (0.69314718055994530942f - 1.0f) + 2.0f * k * e2 * rom;
+}
 VMF_HD void kl_m3_eps_fast(float k, float eps, float* kl, float* g, bool finite_beyond = false) {
   if (k < 1.0f) {
     const float k2 = k * k;
@@ -288,8 +303,7 @@ VMF_HD void kl_m3_eps_fast(float k, float eps, float* kl, float* g, bool finite_
     const float em = fast_exp2(-1.44269504088896340736f * k), e2 = em * em;
     const float D = 1.0f - e2 + 2.0f * eps * em;
     const float rD = fast_rcp(D);
-    // log k - log D as one logarithm: these kernels are bound by the quarter-rate transcendental instructions
-    *kl = fast_log(k * rD) + (0.69314718055994530942f - 1.0f) + 2.0f * k * (e2 - eps * em) * rD;
+    *kl = kl_m3_unified_value(k, eps);
     *g = fast_rcp(k) + k * (2.0f * eps * em * (1.0f - e2) - 4.0f * e2) * (rD * rD);
     return;
   }
@@ -373,10 +387,8 @@ VMF_HD bool kl_value_fast(float kappa, int variant, float* kl_out, float* grad) 
         kl_m3_eps_fast(k, 0.0f, &kl, &g);  // the cancellation-free small-k form
       } else {
         const float e2 = fast_exp(-2.0f * k);
-        const float om = 1.0f - e2;
-        const float rom = fast_rcp(om);
-        // log k - log sinh k + k coth k - 1 with the two O(k) terms cancelled by hand: k coth k - k = 2 k e2 / (1 - e2)
-        kl = fast_log(k) - fast_log(om) + (0.69314718055994530942f - 1.0f) + 2.0f * k * e2 * rom;
+        const float rom = fast_rcp(1.0f - e2);
+        kl = kl_m3_stable_value(k);
         g = fast_rcp(k) - k * (4.0f * e2 * rom * rom);
       }
     } break;
