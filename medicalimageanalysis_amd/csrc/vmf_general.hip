@@ -509,7 +509,7 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
   }
 }
 
-// ---- narrow rows whose width is not a multiple of four (m = 3, 5, 6, 7, 9, 10, 11, 13, 14, 15; fp32, counter noise) -----
+// ---- narrow rows that do not fill a power-of-two lane group (m = 3 .. 31 except 4, 8, 16; fp32, counter noise) -----
 // The lane-group mapping above gives such rows scalar, guarded element accesses and leaves lanes idle (m = 10: four
 // lanes per row, ten of their sixteen slots used).  Here ONE lane owns a row.  A wave's tile of 128 rows is 128 m
 // contiguous floats of mu: it moves between HBM and the wave as a flat array, 16 bytes per lane and access, fully
@@ -518,11 +518,16 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
 // cross-lane sums at all -- writes z back over it, and the slab leaves as a flat array again.  The mu loads are issued
 // before the rejection phase and land while it runs.  Same counters, same noise, same arithmetic as the kernel above.
 // rows per wave: the rejection phase ends in a tail whose cost is per tile, so the narrowest rows take larger tiles (as in
-// the kernel above); the slab stays near 5-8 KiB per wave
+// the kernel above); the slab stays near 5-8 KiB per wave.  2^24 rows, lane-group kernel -> this one, forward / backward ms:
+// m = 10: 0.44 / 0.60 -> 0.32 / 0.34; 12: 0.51 / 0.59 -> 0.36 / 0.41; 17: 0.81 / 1.17 -> 0.49 / 0.58; 20: 0.75 / 0.97 ->
+// 0.52 / 0.69; 24: 0.78 / 1.02 -> 0.61 / 0.82; 31: 1.34 / 1.68 -> 0.75 / 1.07
 #ifndef VMF_RL_TILE_WIDE
 #define VMF_RL_TILE_WIDE 128
 #endif
-constexpr int rl_tile(int m) { return m <= 4 ? 384 : (m <= 7 ? 256 : VMF_RL_TILE_WIDE); }
+#ifndef VMF_RL_MAX
+#define VMF_RL_MAX 31
+#endif
+constexpr int rl_tile(int m) { return m <= 4 ? 384 : (m <= 7 ? 256 : (m <= 16 ? VMF_RL_TILE_WIDE : 64)); }
 template <int M>
 __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_rowlane_kernel(FwdParams<float> p) {
   using T = float;
@@ -707,13 +712,17 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_rowlane_kernel(FwdPara
     for (int i = lane; i < ntile; i += 64) p.logp[tile0 + i] = slc[i];
 }
 
-static bool rowlane_ok(int m) { return m >= 3 && m <= 15 && m % 4 != 0; }
+// widths that take the one-lane-per-row kernels: everything up to VMF_RL_MAX except 4, 8 and 16, whose rows fill their
+// lane group exactly (measured: m = 4 / 8 are 20 % / 10 % slower here, m = 12 -- three of four lanes busy there -- 30 % faster)
+static bool rowlane_ok(int m) { return m >= 3 && m <= VMF_RL_MAX && m != 4 && m != 8 && m != 16; }
 static void launch_rowlane(const FwdParams<float>& p, hipStream_t s) {
   const int64_t tiles = (p.n + rl_tile(p.m) - 1) / rl_tile(p.m);
   const dim3 grid((unsigned)((tiles + WAVES - 1) / WAVES)), block(WAVES * 64);
   switch (p.m) {
 #define VMF_RL(MM) case MM: hipLaunchKernelGGL((vmf_rsample_rowlane_kernel<MM>), grid, block, 0, s, p); break
-    VMF_RL(3); VMF_RL(5); VMF_RL(6); VMF_RL(7); VMF_RL(9); VMF_RL(10); VMF_RL(11); VMF_RL(13); VMF_RL(14); VMF_RL(15);
+    VMF_RL(3); VMF_RL(5); VMF_RL(6); VMF_RL(7); VMF_RL(9); VMF_RL(10); VMF_RL(11); VMF_RL(12); VMF_RL(13); VMF_RL(14);
+    VMF_RL(15); VMF_RL(17); VMF_RL(18); VMF_RL(19); VMF_RL(20); VMF_RL(21); VMF_RL(22); VMF_RL(23); VMF_RL(24); VMF_RL(25);
+    VMF_RL(26); VMF_RL(27); VMF_RL(28); VMF_RL(29); VMF_RL(30); VMF_RL(31);
 #undef VMF_RL
     default: break;
   }
@@ -1029,7 +1038,9 @@ static void launch_bwd_rowlane(const GenParams<float>& p, hipStream_t s) {
   const dim3 grid((unsigned)((tiles + WAVES - 1) / WAVES)), block(WAVES * 64);
   switch (p.m) {
 #define VMF_RL(MM) case MM: hipLaunchKernelGGL((vmf_rsample_bwd_rowlane_kernel<MM>), grid, block, 0, s, p); break
-    VMF_RL(3); VMF_RL(5); VMF_RL(6); VMF_RL(7); VMF_RL(9); VMF_RL(10); VMF_RL(11); VMF_RL(13); VMF_RL(14); VMF_RL(15);
+    VMF_RL(3); VMF_RL(5); VMF_RL(6); VMF_RL(7); VMF_RL(9); VMF_RL(10); VMF_RL(11); VMF_RL(12); VMF_RL(13); VMF_RL(14);
+    VMF_RL(15); VMF_RL(17); VMF_RL(18); VMF_RL(19); VMF_RL(20); VMF_RL(21); VMF_RL(22); VMF_RL(23); VMF_RL(24); VMF_RL(25);
+    VMF_RL(26); VMF_RL(27); VMF_RL(28); VMF_RL(29); VMF_RL(30); VMF_RL(31);
 #undef VMF_RL
     default: break;
   }

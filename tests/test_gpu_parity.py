@@ -715,7 +715,8 @@ def test_general_rsample_predrawn_accept_index_bit_exact(oracle, tag, m, n):
 
 
 @pytest.mark.parametrize("tag", ["f64", "f32"])
-@pytest.mark.parametrize("m,n", [(64, 70000), (512, 3000), (10, 4097), (3, 999), (2, 50001), (4, 3000)])
+@pytest.mark.parametrize("m,n", [(64, 70000), (512, 3000), (10, 4097), (3, 999), (2, 50001), (4, 3000), (12, 1500),
+                                 (17, 777), (22, 4099), (31, 1000)])
 def test_general_rsample_philox_vs_oracle(oracle, tag, m, n):
     gen = np.random.default_rng(200 + m)
     dt = np.float64 if tag == "f64" else np.float32
@@ -811,14 +812,14 @@ def test_general_rsample_two_sample_ks_against_cpu_sampler(oracle):
             assert p > 1e-3, (m, kappa, comp, p)
 
 
-@pytest.mark.parametrize("m", [64, 2, 10, 128, 256, 512, 700, 1024, 2048])
+@pytest.mark.parametrize("m", [64, 2, 10, 12, 21, 31, 128, 256, 512, 700, 1024, 2048])
 def test_general_rsample_every_row_written_once_for_any_grid(m):
     """the forward kernel walks its tiles in a remapped block order (one contiguous eighth of the grid per XCD, plain
     order for the ragged end): for grids of 1 .. 8k+r blocks every row must be produced exactly once -- the output is
     pre-filled with NaN, and the same rows drawn as two shards (other grid sizes, other remaps) must give the same bits"""
     # (wide rows take smaller tiles: about 8192 elements per wave, at least 8 rows; 700 = three passes' worth of
     #  elements in the four-pass instantiation)
-    rows_per_block = {64: 4 * 128, 2: 4 * 512, 10: 4 * 320, 128: 4 * 64, 256: 4 * 32, 512: 4 * 16, 700: 4 * 8, 1024: 4 * 8,
+    rows_per_block = {64: 4 * 128, 2: 4 * 512, 10: 4 * 128, 12: 4 * 128, 21: 4 * 64, 31: 4 * 64, 128: 4 * 64, 256: 4 * 32, 512: 4 * 16, 700: 4 * 8, 1024: 4 * 8,
                       2048: 4 * 8}[m]
     lib, sp = _lib.lib(), _lib.stream_ptr(DEV)
     g = torch.Generator(device=DEV).manual_seed(5)
@@ -842,7 +843,7 @@ def test_general_rsample_every_row_written_once_for_any_grid(m):
         assert torch.equal(torch.cat(parts), z), (m, nb)
 
 
-@pytest.mark.parametrize("m", [2, 10, 64, 256, 512, 700, 1024, 2048])
+@pytest.mark.parametrize("m", [2, 10, 12, 21, 31, 64, 256, 512, 700, 1024, 2048])
 def test_general_backward_writes_every_row_for_any_size(m):
     """the backward kernel gives each wave a width-dependent number of consecutive steps and the host sizes the grid
     from the same rule: for row counts around the step / workgroup boundaries every gradient row must be written
@@ -1021,7 +1022,7 @@ def test_spherical_vae_train_step_batch128():
 
 
 @pytest.mark.parametrize("tag", ["f64", "f32"])
-@pytest.mark.parametrize("m", [2, 3, 10, 64, 130, 512])
+@pytest.mark.parametrize("m", [2, 3, 10, 12, 19, 31, 64, 130, 512])
 def test_general_rsample_normalises_raw_mean_inside_the_kernel(tag, m):
     """normalize_loc=True: raw rows (any positive norm) give the same sample as their unit rows given explicitly, and
     the gradient with respect to the raw rows equals autograd's through F.normalize + the unit-row kernel"""
@@ -1136,7 +1137,7 @@ def test_circle_counter_noise_backward_regenerates_the_forward_sign():
     np.testing.assert_allclose(N(kappa.grad), N(k2.grad), rtol=1e-6, atol=1e-9)
 
 
-@pytest.mark.parametrize("m", [3, 10, 64, 512])
+@pytest.mark.parametrize("m", [3, 10, 12, 23, 31, 64, 512])
 def test_general_backward_vs_autograd_of_restated_forward(m):
     """fp64: the kernel's backward against torch.autograd through the same composition written in torch ops,
     with the Gaussians the kernel regenerates (pre-drawn here) and the accepted proposal held fixed"""
@@ -1190,7 +1191,7 @@ def test_general_backward_vs_autograd_of_restated_forward(m):
     assert torch.isfinite(mu.grad).all() and torch.isfinite(kappa.grad).all()
 
 
-@pytest.mark.parametrize("m", [2, 3, 10, 64, 512])
+@pytest.mark.parametrize("m", [2, 3, 10, 12, 26, 31, 64, 512])
 def test_general_fp32_draws_and_gradients_agree_with_fp64(m):
     """the same rows, the same counters, once in fp32 and once in fp64 (inputs rounded to fp32 first): where both accept
     the same proposal the samples agree to 2e-5 (the fp32 contract is 1e-4) and the backward pass -- hardware
@@ -1262,7 +1263,7 @@ def test_general_m3_fp32_keeps_its_digits_at_the_south_pole():
 
 
 @pytest.mark.parametrize("tag", ["f64", "f32"])
-@pytest.mark.parametrize("m", [2, 3, 10, 64, 512])
+@pytest.mark.parametrize("m", [2, 3, 10, 12, 26, 31, 64, 512])
 def test_general_log_prob_entropy_kl(oracle, tag, m):
     gen = np.random.default_rng(300 + m)
     dt = np.float64 if tag == "f64" else np.float32
