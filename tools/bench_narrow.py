@@ -33,7 +33,7 @@ def timeit(fn, reps=20, warm=10):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--shapes", default="2:27,2:24,3:24,4:24,8:24,10:24,16:24")
+    ap.add_argument("--shapes", default="2:27,2:24,3:24,4:24,8:24,10:24,12:24,16:24,20:24,31:24")
     ap.add_argument("--dtype", default="float32")
     ap.add_argument("--s1", type=int, default=27, help="log2 rows of the S^1 projected-normal case (0: skip)")
     args = ap.parse_args()
