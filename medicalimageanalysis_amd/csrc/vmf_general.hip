@@ -579,6 +579,9 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_rowlane_kernel(FwdPara
     somw[i] = wood_b<T>(kap, M);
   }
   wave_lds_sync();
+#ifdef VMF_ABLATE_PHASE1  // timing ablation only (w fixed): the rejection phase costs 0.06-0.08 ms per 2^24 rows at any width
+  for (int i = lane; i < ntile; i += 64) { sw[i] = 0.5f; somw[i] = 0.75f; }
+#else
   {
     int my = lane, next = 64, k = 0;
     bool active = my < ntile;
@@ -609,6 +612,7 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_rowlane_kernel(FwdPara
       next += __popcll(accm);
     }
   }
+#endif
   // ---- park the tile's mu in the slab ----
   if (full) {
 #pragma unroll
