@@ -6,8 +6,16 @@
 
 template <typename T> struct MT;  // trigonometry the sampler itself never needs
 template <> struct MT<float> {
+  // on the device: the hardware sine / cosine (arguments in revolutions; the angles here are differences of values in
+  // [0, 2 pi], so no range reduction is needed and the error stays near 1e-6 absolute) instead of the library routines
+  // with their large-argument paths
+#if defined(__HIP_DEVICE_COMPILE__)
+  static VMF_HD float sin(float x) { return __builtin_amdgcn_sinf(x * 0.15915494309189533577f); }
+  static VMF_HD float cos(float x) { return __builtin_amdgcn_cosf(x * 0.15915494309189533577f); }
+#else
   static VMF_HD float sin(float x) { return ::sinf(x); }
   static VMF_HD float cos(float x) { return ::cosf(x); }
+#endif
   static VMF_HD float acos(float x) { return ::acosf(x); }
   static VMF_HD float atan2(float y, float x) { return ::atan2f(y, x); }
   static VMF_HD float fmod(float a, float b) { return ::fmodf(a, b); }
@@ -25,7 +33,11 @@ template <> struct MT<double> {
 template <typename T>
 VMF_HD T wrap_2pi(T a) {
   const T two_pi = (T)6.283185307179586476925;
-  T r = MT<T>::fmod(a + two_pi, two_pi);
+  const T s = a + two_pi;
+  // every caller passes an atan2 result, so s lies in [pi, 3 pi]: there the remainder is s or s - 2 pi, and that
+  // subtraction is exact (Sterbenz) -- the same bits as fmod without its division loop
+  if (s >= (T)0 && s < (T)2 * two_pi) return s >= two_pi ? s - two_pi : s;
+  T r = MT<T>::fmod(s, two_pi);
   if (r < (T)0) r += two_pi;
   return r;
 }
