@@ -115,7 +115,9 @@ VMF_HD double log_ive_pos(double v, double lgam_v1, double x) {
 VMF_HD double cheb_sum(const double* c, int n, double t) {
   double b0 = 0.0, b1 = 0.0;
   const double t2 = 2.0 * t;
-#pragma unroll 1
+  // eight terms per trip: the coefficients of a trip arrive in one batch of scalar loads instead of one dependent load
+  // per term (ive(0) / ive(1): 0.22 -> 0.17 ms per 2^24; fully unrolled they would sit in vector registers)
+#pragma unroll 8
   for (int k = n - 1; k >= 1; --k) {
     const double b = c[k] + t2 * b0 - b1;
     b1 = b0;
