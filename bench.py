@@ -51,8 +51,9 @@ HBM_PEAK_GBPS = 8000.0
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # the GPU needs ~10 launches of the headline size to settle its clocks (per-dispatch times in profiles/: 2.2, 2.0,
-    # 1.9 ... then 1.53-1.56 ms), hence the default warm-up
+    # the defaults are the flags the round-end driver passes.  (After an idle period the GPU needs ~15 launches of the
+    # headline size to settle -- per-dispatch times: 1.55, 2.0, 2.1, 1.9 ... then 1.53-1.55 ms -- so the mean of 20 timed
+    # steps after 5 warm-up steps sits 2-3 % above the settled time; kernel_ms_median shows the latter.)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=3, choices=[1, 2, 3, 4, 5])
