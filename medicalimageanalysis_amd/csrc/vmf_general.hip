@@ -1081,18 +1081,43 @@ __global__ __launch_bounds__(256) void vmf_log_norm_kernel(const T* __restrict__
 }
 
 // ---- launch plumbing ---------------------------------------------------------------------------------
-#define VMF_SHAPE_SWITCH(chunks, CALL)                 \
-  do {                                                 \
-    if ((chunks) <= 1) { CALL(1, 1); }                 \
-    else if ((chunks) <= 2) { CALL(2, 1); }            \
-    else if ((chunks) <= 4) { CALL(4, 1); }            \
-    else if ((chunks) <= 8) { CALL(8, 1); }            \
-    else if ((chunks) <= 16) { CALL(16, 1); }          \
-    else if ((chunks) <= 32) { CALL(32, 1); }          \
-    else if ((chunks) <= 64) { CALL(64, 1); }          \
-    else if ((chunks) <= 128) { CALL(64, 2); }         \
-    else if ((chunks) <= 256) { CALL(64, 4); }         \
-    else { CALL(64, 8); }                              \
+// Lanes per row x passes for a row of `chunks` 16-byte chunks: the smallest power of two, or three times a power of two,
+// that holds the row (widths of 3 x 2^k elements -- 96, 192, 384, 768 -- fit exactly; before the three-pass shapes
+// existed they ran with a quarter of their lanes idle, and a row just above a power of two with half of them:
+// 2^21 rows of m = 768 2.52 -> 2.02 ms, 2^23 rows of m = 96 1.43 -> 1.20, of m = 130 3.04 -> 2.03).
+static void pick_shape(int chunks, int* lpr, int* passes) {
+  // (four lanes x three passes for 9-12 chunks measured slower than sixteen lanes with idle ones: m = 40 backward 2x)
+  static const int table[][3] = {{1, 1, 1},   {2, 2, 1},   {4, 4, 1},   {8, 8, 1},    {16, 16, 1},  {24, 8, 3},   {32, 32, 1},
+                                 {48, 16, 3}, {64, 64, 1}, {96, 32, 3}, {128, 64, 2}, {192, 64, 3}, {256, 64, 4}, {512, 64, 8}};
+  for (const auto& t : table)
+    if (chunks <= t[0]) {
+      *lpr = t[1];
+      *passes = t[2];
+      return;
+    }
+  *lpr = 64;
+  *passes = 8;
+}
+#define VMF_SHAPE_SWITCH(chunks, CALL)                                \
+  do {                                                                \
+    int lpr_, passes_;                                                \
+    pick_shape((chunks), &lpr_, &passes_);                            \
+    switch (lpr_ * 16 + passes_) {                                    \
+      case 1 * 16 + 1: CALL(1, 1); break;                             \
+      case 2 * 16 + 1: CALL(2, 1); break;                             \
+      case 4 * 16 + 1: CALL(4, 1); break;                             \
+      case 8 * 16 + 1: CALL(8, 1); break;                             \
+      case 16 * 16 + 1: CALL(16, 1); break;                           \
+      case 8 * 16 + 3: CALL(8, 3); break;                             \
+      case 32 * 16 + 1: CALL(32, 1); break;                           \
+      case 16 * 16 + 3: CALL(16, 3); break;                           \
+      case 64 * 16 + 1: CALL(64, 1); break;                           \
+      case 32 * 16 + 3: CALL(32, 3); break;                           \
+      case 64 * 16 + 2: CALL(64, 2); break;                           \
+      case 64 * 16 + 3: CALL(64, 3); break;                           \
+      case 64 * 16 + 4: CALL(64, 4); break;                           \
+      default: CALL(64, 8); break;                                    \
+    }                                                                 \
   } while (0)
 
 template <typename T, int MODE>
@@ -1133,12 +1158,9 @@ static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   p.ka = make_philox_arg(seed, offset, offset_dev);
   const bool vec = (m % 4 == 0) && (mu_stride % 4 == 0) && aligned16(mu) && aligned16(z) && (!gauss || aligned16(gauss));
   const int chunks = (m + 3) / 4;
-  int lpr = 1;
-  while (lpr < chunks && lpr < 64) lpr *= 2;
-  const int passes = (chunks + lpr - 1) / lpr;
-  const bool full = vec && (passes == 1 || passes == 2 || passes == 4 || passes == 8) && m == 4 * lpr * passes;
-  // the pass count of the instantiation VMF_SHAPE_SWITCH picks (a power of two), which sets the tile size
-  const int kpasses = chunks <= 64 ? 1 : (chunks <= 128 ? 2 : (chunks <= 256 ? 4 : 8));
+  int lpr, kpasses;  // the instantiation VMF_SHAPE_SWITCH picks: it sets the tile size
+  pick_shape(chunks, &lpr, &kpasses);
+  const bool full = vec && m == 4 * lpr * kpasses;
   const int64_t n_tiles = (n + tile_rows(lpr, kpasses) - 1) / tile_rows(lpr, kpasses);
   int64_t gb = (n_tiles + WAVES - 1) / WAVES;
   // One tile per wave, every tile its own wave: workgroups are dispatched in index order and the kernel maps them
@@ -1224,11 +1246,9 @@ static int rsample_bwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   const bool vec = (m % 4 == 0) && (mu_stride % 4 == 0) && aligned16(mu) && aligned16(gz) && aligned16(dmu) &&
                    (!gauss || aligned16(gauss));
   const int chunks = (m + 3) / 4;
-  int lpr = 1;
-  while (lpr < chunks && lpr < 64) lpr *= 2;
+  int lpr, kpasses;  // the instantiation VMF_SHAPE_SWITCH picks: it sets the steps per wave
+  pick_shape(chunks, &lpr, &kpasses);
   const int64_t steps = (n + (64 / lpr) - 1) / (64 / lpr);
-  // the pass count of the instantiation VMF_SHAPE_SWITCH picks, which sets the steps per wave
-  const int kpasses = chunks <= 64 ? 1 : (chunks <= 128 ? 2 : (chunks <= 256 ? 4 : 8));
   const int spw = bwd_steps(lpr, kpasses);
   const int64_t waves = (steps + spw - 1) / spw;
   int64_t gb = (waves + WAVES - 1) / WAVES;
@@ -1367,8 +1387,8 @@ static int log_prob_t(const void* mu, int64_t mu_stride, const void* kappa, int6
   const bool vec = (m % 4 == 0) && (mu_stride % 4 == 0) && aligned16(mu) && aligned16(x) && (!dmu || aligned16(dmu)) &&
                    (!dx || aligned16(dx));
   const int chunks = (m + 3) / 4;
-  int lpr = 1;
-  while (lpr < chunks && lpr < 64) lpr *= 2;
+  int lpr, kpasses;
+  pick_shape(chunks, &lpr, &kpasses);
   const int64_t steps = (n + (64 / lpr) - 1) / (64 / lpr);
   const int64_t waves = (steps + LP_STEPS - 1) / LP_STEPS;
   int64_t gb = (waves + WAVES - 1) / WAVES;

@@ -724,7 +724,7 @@ def test_general_rsample_predrawn_accept_index_bit_exact(oracle, tag, m, n):
 
 @pytest.mark.parametrize("tag", ["f64", "f32"])
 @pytest.mark.parametrize("m,n", [(64, 70000), (512, 3000), (10, 4097), (3, 999), (2, 50001), (4, 3000), (12, 1500),
-                                 (17, 777), (22, 4099), (31, 1000)])
+                                 (17, 777), (22, 4099), (31, 1000), (96, 3000), (70, 1001), (768, 300)])
 def test_general_rsample_philox_vs_oracle(oracle, tag, m, n):
     gen = np.random.default_rng(200 + m)
     dt = np.float64 if tag == "f64" else np.float32
@@ -820,14 +820,14 @@ def test_general_rsample_two_sample_ks_against_cpu_sampler(oracle):
             assert p > 1e-3, (m, kappa, comp, p)
 
 
-@pytest.mark.parametrize("m", [64, 2, 10, 12, 21, 31, 128, 256, 512, 700, 1024, 2048])
+@pytest.mark.parametrize("m", [64, 2, 10, 12, 21, 31, 96, 128, 256, 512, 700, 768, 1024, 2048])
 def test_general_rsample_every_row_written_once_for_any_grid(m):
     """the forward kernel walks its tiles in a remapped block order (one contiguous eighth of the grid per XCD, plain
     order for the ragged end): for grids of 1 .. 8k+r blocks every row must be produced exactly once -- the output is
     pre-filled with NaN, and the same rows drawn as two shards (other grid sizes, other remaps) must give the same bits"""
     # (wide rows take smaller tiles: about 8192 elements per wave, at least 8 rows; 700 = three passes' worth of
     #  elements in the four-pass instantiation)
-    rows_per_block = {64: 4 * 128, 2: 4 * 512, 10: 4 * 128, 12: 4 * 128, 21: 4 * 64, 31: 4 * 64, 128: 4 * 64, 256: 4 * 32, 512: 4 * 16, 700: 4 * 8, 1024: 4 * 8,
+    rows_per_block = {64: 4 * 128, 2: 4 * 512, 10: 4 * 128, 12: 4 * 128, 21: 4 * 64, 31: 4 * 64, 96: 4 * 85, 768: 4 * 10, 128: 4 * 64, 256: 4 * 32, 512: 4 * 16, 700: 4 * 10, 1024: 4 * 8,
                       2048: 4 * 8}[m]
     lib, sp = _lib.lib(), _lib.stream_ptr(DEV)
     g = torch.Generator(device=DEV).manual_seed(5)
@@ -851,7 +851,7 @@ def test_general_rsample_every_row_written_once_for_any_grid(m):
         assert torch.equal(torch.cat(parts), z), (m, nb)
 
 
-@pytest.mark.parametrize("m", [2, 10, 12, 21, 31, 64, 256, 512, 700, 1024, 2048])
+@pytest.mark.parametrize("m", [2, 10, 12, 21, 31, 64, 96, 256, 512, 700, 768, 1024, 2048])
 def test_general_backward_writes_every_row_for_any_size(m):
     """the backward kernel gives each wave a width-dependent number of consecutive steps and the host sizes the grid
     from the same rule: for row counts around the step / workgroup boundaries every gradient row must be written
