@@ -200,7 +200,11 @@ struct FwdParams {
 // wait can be placed by hand: the memory counter retires operations in order, and a compiler-placed wait at the loop
 // head would also wait for the store issued just before it -- the store's whole round trip, every step.  Rules that
 // keep this correct: the destination is touched by nothing between prefetch_issue() and prefetch_wait(); the wait
-// names the destination as an in/out operand so every use is ordered after it; vmcnt(0) over-waits at worst.
+// names the destination as an in/out operand so every use is ordered after it; vmcnt(0) over-waits at worst; and the
+// destination must never be spilled between the two (the compiler would reuse the register while the load is in flight
+// and the late data would land in whatever lives there then -- an instantiation squeezed under a register cap faulted
+// that way): every instantiation that prefetches must have a private segment of zero, which a test reads off the built
+// library.
 // cache modifiers of the streaming kernel's mu load and z store.  A/B in one process on 2^24 x 64 rows (plain load +
 // plain store = 1.000): nt store 0.989, nt load + nt store 0.974, nt load + system-scope nt store 0.967; scope bits
 // without nt 0.985.  Every byte is touched once, so nothing is worth keeping in L2.

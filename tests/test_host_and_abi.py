@@ -361,3 +361,35 @@ def test_allreduce_scalars_argument_checks():
     assert lib.vmf_allreduce_scalars(C.c_void_p(1), buf, 0, None) == -1
     assert lib.vmf_allreduce_scalars(C.c_void_p(1), buf, 65, None) == -1
     assert b"count" in lib.vmf_last_error_string()
+
+
+def test_streaming_kernels_with_hand_placed_prefetch_use_no_scratch(tmp_path):
+    """The fp32 streaming instantiations of vmf_rsample_fwd_kernel (MODE 2) load the next rows from inline asm and wait
+    for them by hand: between the two, the compiler believes the destination registers already hold the data.  That is
+    only sound while those registers are never spilled (a spilled destination is reused while the load is in flight and
+    overwritten when it lands).  Every such instantiation in the built library must have a private segment of zero."""
+    import shutil
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("llvm-objdump / llvm-readelf not found")
+    from medicalimageanalysis_amd import _lib
+    so = tmp_path / "libvmf_hip.so"
+    shutil.copy(_lib.library_path(), so)
+    subprocess.run([objdump, "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path, timeout=300)
+    seen = 0
+    for f in sorted(tmp_path.iterdir()):
+        if "gfx950" not in f.name:
+            continue
+        notes = subprocess.run([readelf, "--notes", str(f)], check=True, capture_output=True, text=True, timeout=300).stdout
+        name = None
+        for line in notes.splitlines():
+            line = line.strip()
+            if line.startswith(".name:"):
+                name = line.split(":", 1)[1].strip()
+            elif line.startswith(".private_segment_fixed_size:") and name:
+                # _Z22vmf_rsample_fwd_kernelIfLi<LPR>ELi<P>ELi2EEv...: T = float, MODE = 2
+                if re.match(r"_Z22vmf_rsample_fwd_kernelIfLi\d+ELi\d+ELi2EEv", name):
+                    seen += 1
+                    assert int(line.split(":")[1]) == 0, (name, line)
+                name = None
+    assert seen >= 10, seen
