@@ -1093,13 +1093,6 @@ static void pick_shape(int chunks, int* lpr, int* passes) {
   // (four lanes x three passes for 9-12 chunks measured slower than sixteen lanes with idle ones: m = 40 backward 2x)
   static const int table[][3] = {{1, 1, 1},   {2, 2, 1},   {4, 4, 1},   {8, 8, 1},    {16, 16, 1},  {24, 8, 3},   {32, 32, 1},
                                  {48, 16, 3}, {64, 64, 1}, {96, 32, 3}, {128, 64, 2}, {192, 64, 3}, {256, 64, 4}, {512, 64, 8}};
-#ifdef VMF_EXP_SHAPE16_LPR  // experiment: another split of the 16-chunk row (m = 64)
-  if (chunks == 16) {
-    *lpr = VMF_EXP_SHAPE16_LPR;
-    *passes = 16 / VMF_EXP_SHAPE16_LPR;
-    return;
-  }
-#endif
   for (const auto& t : table)
     if (chunks <= t[0]) {
       *lpr = t[1];
@@ -1109,11 +1102,6 @@ static void pick_shape(int chunks, int* lpr, int* passes) {
   *lpr = 64;
   *passes = 8;
 }
-#ifdef VMF_EXP_SHAPE16_LPR
-#define VMF_EXP_CASES(CALL) case VMF_EXP_SHAPE16_LPR * 16 + 16 / VMF_EXP_SHAPE16_LPR: CALL(VMF_EXP_SHAPE16_LPR, 16 / VMF_EXP_SHAPE16_LPR); break;
-#else
-#define VMF_EXP_CASES(CALL)
-#endif
 #define VMF_SHAPE_SWITCH(chunks, CALL)                                \
   do {                                                                \
     int lpr_, passes_;                                                \
@@ -1132,7 +1120,6 @@ static void pick_shape(int chunks, int* lpr, int* passes) {
       case 64 * 16 + 2: CALL(64, 2); break;                           \
       case 64 * 16 + 3: CALL(64, 3); break;                           \
       case 64 * 16 + 4: CALL(64, 4); break;                           \
-      VMF_EXP_CASES(CALL)                                             \
       default: CALL(64, 8); break;                                    \
     }                                                                 \
   } while (0)
