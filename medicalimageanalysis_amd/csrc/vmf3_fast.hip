@@ -224,10 +224,12 @@ constexpr int V3_OUTER_J = 256;            // loc rows per block: 768 flattened 
 constexpr int V3_OUTER_E = 3 * V3_OUTER_J;
 constexpr int V3_OUTER_MAX_RPW = 16;       // rows i per wave (4 waves per block)
 // smallest grid worth keeping when a larger tile is possible.  The backward wants large tiles (its column partials shrink
-// with the tile height: (4096, 4096, 3) ran 0.057 / 0.072 / 0.127 ms at 1024 / 2048 / 4096 blocks); the forward only
-// amortises a prologue and ran 0.0412 / 0.0402 / 0.0387 ms.
+// with the tile height: (4096, 4096, 3) ran 0.057 / 0.072 / 0.127 ms at 1024 / 2048 / 4096 blocks).  The forward only
+// amortises a prologue over its tile and runs best with the smallest one, one row per wave: (4096, 4096, 3) 0.0412 /
+// 0.0387 / 0.0359 / 0.0328 ms at 1024 / 4096 / 8192 / 16384 blocks, (12288, 12288, 3) 0.338 -> 0.310 ms -- hence a floor
+// no problem reaches.
 #ifndef VMF3_OUTER_MIN_BLOCKS_FWD
-#define VMF3_OUTER_MIN_BLOCKS_FWD 4096
+#define VMF3_OUTER_MIN_BLOCKS_FWD (1 << 30)
 #endif
 #ifndef VMF3_OUTER_MIN_BLOCKS_BWD
 #define VMF3_OUTER_MIN_BLOCKS_BWD 1024

@@ -547,7 +547,10 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
 #ifndef VMF_RL_MAX
 #define VMF_RL_MAX 31
 #endif
-constexpr int rl_tile(int m) { return m <= 4 ? 384 : (m <= 7 ? 256 : (m <= 16 ? VMF_RL_TILE_WIDE : 64)); }
+#ifndef VMF_RL_TILE_WIDER
+#define VMF_RL_TILE_WIDER 64
+#endif
+constexpr int rl_tile(int m) { return m <= 4 ? 384 : (m <= 7 ? 256 : (m <= 16 ? VMF_RL_TILE_WIDE : VMF_RL_TILE_WIDER)); }
 template <int M>
 __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_rowlane_kernel(FwdParams<float> p) {
   using T = float;

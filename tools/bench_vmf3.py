@@ -98,7 +98,7 @@ def main():
     for given in ((False, True) if "--outer-only" not in sys.argv else ()):
         nz = 16 if given else 0
         case(f"rows, B = 2^24 -> (B, 3)", (n, 3), (n,), given, n * (28 + nz), n * (44 + nz))
-    for B in (4096, 128):
+    for B in ([int(x) for x in os.environ["VMF3_BENCH_B"].split(",")] if "VMF3_BENCH_B" in os.environ else (4096, 128)):
         for given in (False, True):
             # forward: z written once; backward: grad z read once (the per-row operands are negligible)
             case(f"outer, B = {B} -> ({B}, {B}, 3)", (B, 3), (B, 1), given, B * B * 12, B * B * 12)
