@@ -44,6 +44,32 @@ for v in args.only.split(","):
     ms = timeit(f, reps=args.reps, warm=min(10, args.reps))
     print(f"| KL sum {v} fp32 2^27, kappa log-uniform {rng_} | {ms:.3f} | {n * 4 / ms / 1e6:.0f} | {n * 4 / ms / 8e7:.1f} % |",
           flush=True)
+# fused ELBO through the C ABI: x (B, D) against x_hat (B, B, D), the reference's broadcast (model/spherical_vae.py:133-138)
+for B in (128, 1024):
+    D = 784
+    x = torch.rand(B, D, device=DEV, generator=g)
+    xh = torch.rand(B, B, D, device=DEV, generator=g)
+    kp = torch.rand(B, 1, device=DEV, generator=g) * 50 + 1
+    loss = torch.empty((), device=DEV)
+    wse = torch.empty(_lib.ELBO_WORKSPACE_DOUBLES, device=DEV, dtype=torch.float64)
+    dxh, dkp, one1 = torch.empty_like(xh), torch.empty_like(kp), torch.ones((), device=DEV)
+
+    def ef():
+        rc = lib.vmf_elbo_fwd(_lib.ptr(x), _lib.ptr(xh), _lib.ptr(kp), _lib.ptr(loss), None, _lib.ptr(wse), 1.0 / xh.numel(),
+                              1.0 / B, x.numel(), xh.numel(), B, klmod.VARIANTS["spherical"], _lib.VMF_F32, sp)
+        assert rc == 0
+
+    def eb():
+        rc = lib.vmf_elbo_bwd(_lib.ptr(x), _lib.ptr(xh), _lib.ptr(kp), _lib.ptr(one1), _lib.ptr(dxh), _lib.ptr(dkp),
+                              1.0 / xh.numel(), 1.0 / B, x.numel(), xh.numel(), B, klmod.VARIANTS["spherical"], _lib.VMF_F32, sp)
+        assert rc == 0
+    ms = timeit(ef, reps=args.reps, warm=min(10, args.reps))
+    print(f"| fused ELBO forward, x_hat ({B},{B},{D}) fp32 | {ms:.4f} | {xh.numel() * 4 / ms / 1e6:.0f} | "
+          f"{xh.numel() * 4 / ms / 8e7:.1f} % |", flush=True)
+    ms = timeit(eb, reps=args.reps, warm=min(10, args.reps))
+    print(f"| fused ELBO backward, x_hat ({B},{B},{D}) fp32 | {ms:.4f} | {xh.numel() * 8 / ms / 1e6:.0f} | "
+          f"{xh.numel() * 8 / ms / 8e7:.1f} % |", flush=True)
+    del x, xh, dxh
 if not args.no_ive:
     kg = kap[: 1 << 24].clone()
     dk = torch.empty_like(kg)
