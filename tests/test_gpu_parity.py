@@ -1845,3 +1845,15 @@ def test_kernels_write_nothing_outside_their_outputs(pad):
         torch.cuda.synchronize()
         assert _margins_intact(ob, n, pad) and _margins_intact(db, n, pad), variant
         assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(dkap).all())
+
+
+def test_randomised_layouts_widths_and_offsets_against_the_oracle():
+    """a short run of the randomised sweep (tests/fuzz_parity.py: widths 2..300, padded rows, misaligned bases, row
+    offsets beyond 2^33): every case asserts inside the sweep; here the totals are looked at"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "fuzz_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.sweep(250, 11)
+    assert out["rows"] > 100000 and out["accept_flips"] <= 10, out
+    assert out["worst"]["z"] < 2e-5 and out["worst"]["layout"] < 2e-6, out
