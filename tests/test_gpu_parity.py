@@ -1857,3 +1857,15 @@ def test_randomised_layouts_widths_and_offsets_against_the_oracle():
     out = mod.sweep(250, 11)
     assert out["rows"] > 100000 and out["accept_flips"] <= 10, out
     assert out["worst"]["z"] < 2e-5 and out["worst"]["layout"] < 2e-6, out
+
+
+def test_randomised_broadcast_shapes_of_the_m3_sampler_against_the_torch_restatement():
+    """a short run of tests/fuzz_vmf3.py: random loc / scale / sample shapes and operand views, draw and gradients
+    against the reference's op sequence under autograd (every case asserts inside the sweep)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_vmf3", os.path.join(os.path.dirname(__file__), "fuzz_vmf3.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.sweep(120, 21)
+    assert len(out["kinds"]) == 3 and min(out["kinds"].values()) >= 10, out  # GENERAL, ROWS and OUTER all exercised
+    assert out["worst"]["z64"] < 1e-12 and out["worst"]["z32"] < 2e-5, out
