@@ -1869,3 +1869,17 @@ def test_randomised_broadcast_shapes_of_the_m3_sampler_against_the_torch_restate
     out = mod.sweep(120, 21)
     assert len(out["kinds"]) == 3 and min(out["kinds"].values()) >= 10, out  # GENERAL, ROWS and OUTER all exercised
     assert out["worst"]["z64"] < 1e-12 and out["worst"]["z32"] < 2e-5, out
+
+
+
+def test_randomised_orders_and_arguments_of_ive_against_scipy():
+    """a short run of tests/fuzz_ive.py: the hot path's orders, random real orders up to 400 and arguments over twelve
+    decades (a quarter of them around the order, where the regimes hand over) against scipy.special.ive, the function
+    the reference calls (sampler/ive.py:14-33)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_ive", os.path.join(os.path.dirname(__file__), "fuzz_ive.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    w = mod.sweep(40, 31, n_x=8000)["worst"]
+    assert w["ive"][0] < 2e-12 and w["dive"][0] < 2e-12 and w["ratio"][0] < 3e-12 and w["log_ive"][0] < 1e-13, w
+    assert w["ive32"][0] < 1.2e-7, w
