@@ -36,6 +36,7 @@ _FLAT_ALIASES = {
     "ive": "medicalimageanalysis_amd.sampler.ive",
     "circular_VAE": "medicalimageanalysis_amd.model.circular_vae",
     "s1_vae": "medicalimageanalysis_amd.model.s1_vae",
+    "geometry": "medicalimageanalysis_amd.geometry",   # compute_curvature_profile (regular_cnn/main.py:12)
 }
 
 
@@ -74,7 +75,7 @@ def install_aliases(flat=False):
     Only the leaf modules this package replaces are registered; `sampler` and `model` themselves stay the caller's
     packages when they exist, so `from model.train import *` (main.py:4) still finds the reference's own train.py.
     flat=True also registers the bare names the CNN / S^1 experiments use (`von_mises_fisher`, `ive`, `circular_VAE`,
-    `s1_vae`); they are generic names, hence opt-in."""
+    `s1_vae`, `geometry`); they are generic names, hence opt-in."""
     for alias, target in _ALIASES.items():
         parent, leaf = alias.split(".")
         mod = importlib.import_module(target)

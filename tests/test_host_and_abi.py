@@ -161,7 +161,7 @@ def test_generator_state_roundtrip():
 
 def _alias_sandbox():
     """snapshot of the module names install_aliases() may touch"""
-    names = ("sampler", "model", "dataloader", "von_mises_fisher", "ive", "circular_VAE", "s1_vae")
+    names = ("sampler", "model", "dataloader", "von_mises_fisher", "ive", "circular_VAE", "s1_vae", "geometry")
     return {k: v for k, v in sys.modules.items() if k.split(".")[0] in names}, names
 
 
@@ -228,7 +228,8 @@ def test_aliases_leave_the_callers_own_model_package_alone(tmp_path):
 
 def test_flat_module_names_of_the_cnn_and_s1_experiments():
     """CNN_experiment/circular_VAE.py:5 (`from von_mises_fisher import *`), CNN_experiment/von_mises_fisher.py:3
-    (`from ive import ive`), CNN_experiment/train_experiment.py:9, regular_cnn/main.py:11"""
+    (`from ive import ive`), CNN_experiment/train_experiment.py:9, regular_cnn/main.py:11-12,
+    invariant_cnn/main_invariant.py:10-11"""
     import medicalimageanalysis_amd as pkg
     from medicalimageanalysis_amd.sampler.von_mises_fisher import VonMisesFisher3DLogProb
 
@@ -237,7 +238,8 @@ def test_flat_module_names_of_the_cnn_and_s1_experiments():
         pkg.install_aliases(flat=True)
         ns = {}
         exec("from von_mises_fisher import *\nfrom ive import ive\nfrom circular_VAE import CircularVAE\n"
-             "from s1_vae import S1_VAE, loss_function\n", ns)
+             "from s1_vae import S1_VAE, loss_function\nfrom geometry import compute_curvature_profile\n", ns)
+        assert ns["compute_curvature_profile"].__module__ == "medicalimageanalysis_amd.geometry"
         assert ns["VonMisesFisher3D"] is VonMisesFisher3DLogProb and hasattr(ns["VonMisesFisher3D"], "log_prob")
         for name in ("math", "torch", "ive", "Distribution", "constraints", "CircularVAE", "S1_VAE", "loss_function"):
             assert name in ns, name
