@@ -306,7 +306,7 @@ class VAETrainStep:
                         decoder_width=128, decoder_depth=4, dropout_p=0.1, device=str(dev), gamma=1.0, beta=0.01)
         torch.manual_seed(rank)
         self.model = HypersphericalVAE(self.cfg)
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, capturable=True)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, capturable=True, fused=True)
         self.x = torch.rand(B, 784, device=dev)
         torch.distributions.Distribution.set_default_validate_args(False)
 

@@ -18,8 +18,8 @@ DEV = torch.device("cuda:0")
 STEPS = 10
 
 
-def count(model, fold):
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+def count(model, fold, fused=False):
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True, **({'fused': True} if fused else {}))
     x = torch.rand(128, 784, device=DEV)
 
     def step():
@@ -50,16 +50,16 @@ def main():
     torch.distributions.Distribution.set_default_validate_args(False)
     base = dict(extrinsic_dim=784, sftbeta=1.0, encoder_width=128, encoder_depth=4, decoder_width=128, decoder_depth=4,
                 dropout_p=0.1, device="cuda", gamma=1.0, beta=0.01)
-    print("| model (batch 128, 28x28) | heads | kernel launches per step | of them libvmf_hip kernels |")
-    print("|---|---|---|---|")
+    print("| model (batch 128, 28x28) | heads | Adam | kernel launches per step | of them libvmf_hip kernels |")
+    print("|---|---|---|---|---|")
     for name, cls, latent in (("SphericalVAE, latent S^2 (z is (128,128,3))", SphericalVAE, 3),
                               ("HypersphericalVAE, latent S^9", HypersphericalVAE, 10)):
-        for fold in (False, True):
+        for fold, fused in ((False, False), (True, False), (True, True)):
             torch.manual_seed(0)
             model = cls(dict(base, latent_dim=latent))
-            total, ours = count(model, fold)
-            print(f"| {name} | {'folded into the sampler' if fold else 'torch ops (encode / reparemetrize)'} | {total:.1f} | "
-                  f"{ours:.1f} |", flush=True)
+            total, ours = count(model, fold, fused)
+            print(f"| {name} | {'folded into the sampler' if fold else 'torch ops (encode / reparemetrize)'} | "
+                  f"{'fused (one launch)' if fused else 'for-each (torch default)'} | {total:.1f} | {ours:.1f} |", flush=True)
 
 
 if __name__ == "__main__":
