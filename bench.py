@@ -314,14 +314,15 @@ class VAETrainStep:
             z, x_mu, params = mdl(xb)
             return mdl._elbo(xb, x_mu, params)
         self.loss_fn = loss_fn
-        self.graphed = GraphedTrainStep(self.model, self.opt, loss_fn, [self.x], warmup=3)
+        self.graphed = GraphedTrainStep(self.model, self.opt, loss_fn, [self.x], warmup=3, tune_gemms=True)
         self.loss = None
         self.units, self.dtype, self.unit = B, "f32", "samples/s"
         self.bytes_per_unit = (2 * 10 + 1) * 4
         self.kernel = "vmf_rsample_fwd_kernel (m=10)"
         self.metric = f"Spherical VAE train step samples/sec (28x28, batch {B}, latent S^9)"
         self.workload = (f"HypersphericalVAE (784-128x5-S^9-128x5-784, softplus MLPs) forward + ELBO + backward + Adam on a "
-                         f"synthetic batch of {B}, one HIP graph replay per step, fp32, independent replica per GPU")
+                         f"synthetic batch of {B}, one HIP graph replay per step (fused Adam update; the nn.Linear GEMM kernels chosen "
+                         f"by PyTorch's TunableOp during warm-up), fp32, independent replica per GPU")
         self.config = {"batch_per_gpu": B, "latent_dim": 10, "sharding": "replicas (no gradient exchange)"}
 
     def step(self, i, ev):

@@ -6,6 +6,9 @@ backward + optimizer step can be captured once and replayed as one graph launch.
 torch's generator is capture-aware (VMF_RNG=torch), and the in-kernel Philox streams read their call counter from
 device memory (rng.PhiloxGenerator.enable_device_counter, which GraphedTrainStep always turns on).
 """
+import os
+import tempfile
+
 import torch
 
 from . import rng
@@ -18,9 +21,14 @@ class GraphedTrainStep:
     (e.g. torch.optim.Adam(..., capturable=True, fused=True): the fused update is one launch for all parameters where
     the default for-each update is a dozen per step -- the S^9 step at batch 128 replays in 0.70 ms with it against
     0.84 ms without).  Inputs are copied into static buffers, so their shapes and
-    dtypes are fixed at construction.  The returned loss is a static tensor that the next call overwrites."""
+    dtypes are fixed at construction.  The returned loss is a static tensor that the next call overwrites.
 
-    def __init__(self, model, optimizer, loss_fn, example_inputs, warmup=3, generator=None):
+    tune_gemms=True lets PyTorch's TunableOp choose the GEMM kernel of every nn.Linear shape during the warm-up steps
+    (a few seconds; its log of choices goes to the temp directory unless PYTORCH_TUNABLEOP_FILENAME names a file).  The MLP bodies of the VAEs are stock nn.Linear; at batch 128 the
+    default choice runs a 128 x 128 x 128 product in ONE workgroup (11-16 us each, a third of the replay), the tuned
+    ones take 6 us: the S^9 step replays in 0.48 ms instead of 0.70."""
+
+    def __init__(self, model, optimizer, loss_fn, example_inputs, warmup=3, generator=None, tune_gemms=False):
         for group in optimizer.param_groups:
             if "capturable" in group and not group["capturable"]:
                 raise ValueError("GraphedTrainStep needs an optimizer with capturable=True (its step counter must "
@@ -35,9 +43,19 @@ class GraphedTrainStep:
         (generator or rng.default_generator).enable_device_counter(dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
+        tuner = torch.cuda.tunable if tune_gemms else None
+        if tuner is not None:
+            was = (tuner.is_enabled(), tuner.tuning_is_enabled())
+            tuner.enable(True)
+            tuner.tuning_enable(True)
+            if "PYTORCH_TUNABLEOP_FILENAME" not in os.environ:  # TunableOp logs its choices as it goes: not into the cwd
+                tuner.set_filename(os.path.join(tempfile.gettempdir(), f"vmf_tunableop_{os.getpid()}.csv"))
         with torch.cuda.stream(side):  # warm-up off the capture stream: lazy initialisations, optimizer state
             for _ in range(warmup):
                 self._eager_step()
+        if tuner is not None:
+            torch.cuda.synchronize(dev)
+            tuner.tuning_enable(was[1])  # the choices made stay in use (also inside the capture); no further tuning
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)

@@ -1714,6 +1714,38 @@ def test_graphed_general_m_step_under_default_torch_rng(monkeypatch):
     assert losses[-1] < losses[0]
 
 
+def test_graphed_step_with_fused_adam_and_tuned_gemms(tmp_path, monkeypatch):
+    """GraphedTrainStep(tune_gemms=True): PyTorch's TunableOp picks the nn.Linear kernels during the warm-up steps, the
+    capture uses them, tuning is switched off again afterwards and nothing is written into the working directory"""
+    from medicalimageanalysis_amd.graph import GraphedTrainStep
+    from medicalimageanalysis_amd.model.hyperspherical_vae import HypersphericalVAE
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("PYTORCH_TUNABLEOP_FILENAME", raising=False)
+    cfg = dict(extrinsic_dim=784, latent_dim=10, sftbeta=1.0, encoder_width=64, encoder_depth=2, decoder_width=64,
+               decoder_depth=2, dropout_p=0.0, device="cuda", gamma=1.0, beta=0.01)
+    x = torch.rand(128, 784, device=DEV)
+
+    def loss_fn(model, xb):
+        z, x_mu, params = model(xb)
+        return model._elbo(xb, x_mu, params)
+
+    tuner = torch.cuda.tunable
+    before = (tuner.is_enabled(), tuner.tuning_is_enabled())
+    try:
+        torch.manual_seed(0)
+        model = HypersphericalVAE(cfg)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True, fused=True)
+        step = GraphedTrainStep(model, opt, loss_fn, [x], warmup=2, tune_gemms=True)
+        assert tuner.is_enabled() and tuner.tuning_is_enabled() == before[1]
+        assert len(tuner.get_results()) > 0  # shapes were tuned
+        losses = [float(step(x)) for _ in range(30)]
+    finally:
+        tuner.tuning_enable(before[1])
+        tuner.enable(before[0])
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    assert list(tmp_path.iterdir()) == []
+
+
 def test_error_conventions():
     loc = torch.randn(4, 3, device=DEV)
     with pytest.raises(AssertionError):
