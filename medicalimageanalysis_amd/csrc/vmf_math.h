@@ -196,20 +196,34 @@ VMF_HD T kl_value(T kappa, int variant, const KlBessel& kb, T* grad) {
         kl = k2 * ((T)(1.0 / 6.0) + k2 * ((T)(-1.0 / 60.0) + k2 * (T)(1.0 / 567.0)));
         g = k * ((T)(1.0 / 3.0) + k2 * ((T)(-1.0 / 15.0) + k2 * (T)(6.0 / 567.0)));
       } else {
+        // log k - log sinh k + k coth k - 1 with log sinh k = k + log(1 - e^-2k) - ln 2 and k coth k = k + 2k e^-2k /
+        // (1 - e^-2k): the two k cancel on paper, so no rounding of k (1e-16 k in double) reaches the result
         T e2 = M<T>::exp((T)-2 * k);
-        T coth = ((T)1 + e2) / ((T)1 - e2);
-        T log_sinh = k + M<T>::log1p(-e2) - (T)0.69314718055994530942;
-        kl = M<T>::log(k) - log_sinh + k * coth - (T)1;
-        T csch2 = (T)4 * e2 / (((T)1 - e2) * ((T)1 - e2));
+        T om = (T)1 - e2;
+        kl = M<T>::log(k) - M<T>::log1p(-e2) + (T)(0.69314718055994530942 - 1.0) +
+             (e2 > (T)0 ? (T)2 * (k * e2) / om : (T)0);  // (an infinite k meets e2 = 0)
+        T csch2 = (T)4 * e2 / (om * om);
         g = (T)1 / k - k * csch2;
       }
     } break;
     case VMF_KL_STABLE_M2: if constexpr (BESSEL) {
-      double k = (double)kappa;
-      double e0 = ive_eval(kb.o0, k), e1 = ive_eval(kb.o1, k);
-      double A = e1 / e0;
-      kl = (T)(k * A - (::log(e0) + ::fabs(k)));
-      g = (T)(k - A - k * A * A);
+      double k = ::fabs((double)kappa);
+      if (k > 200.0) {
+        // k A - log I0 = (log 2 pi k - 1) / 2 - 1/(4k) - 3/(16k^2) - 25/(96k^3) - 65/(128k^4) - 3219/(2560k^5) - ...
+        // (from the large-argument expansions of I0 and I1, A&S 9.7.1); the first term left out is 3.8 / k^6 < 6e-14,
+        // while k (1 - A) formed from the two scaled Bessel values loses 2 k ulp (1e-13 at 200, everything at 1e16)
+        double x = 1.0 / k;
+        kl = (T)(0.5 * (::log(6.283185307179586476925 * k) - 1.0) -
+                 x * (0.25 + x * (3.0 / 16.0 + x * (25.0 / 96.0 + x * (65.0 / 128.0 + x * (3219.0 / 2560.0))))));
+        double gg = x * (0.5 + x * (0.25 + x * (3.0 / 8.0 + x * (25.0 / 32.0 + x * (65.0 / 32.0 + x * (3219.0 / 512.0))))));
+        g = (T)(kappa < 0 ? -gg : gg);
+      } else {
+        double e0 = ive_eval(kb.o0, k), e1 = ive_eval(kb.o1, k);
+        double A = e1 / e0;
+        kl = (T)(k * A - (::log(e0) + k));
+        double gg = k - A - k * A * A;
+        g = (T)(kappa < 0 ? -gg : gg);
+      }
     } break;
     default:
       kl = (T)NAN; g = (T)NAN;
@@ -217,6 +231,8 @@ VMF_HD T kl_value(T kappa, int variant, const KlBessel& kb, T* grad) {
   *grad = g;
   return kl;
 }
+
+VMF_HD float kl_m2_value_f32(float a);  // (defined below, next to its coefficient tables)
 
 // ---- fp32 fast path of the KL variants ------------------------------------------------------------------------
 // The accurate version above spends ~500 instructions per element in libm's sinh / cosh / log / exp (and, for the
@@ -275,7 +291,7 @@ VMF_HD float kl_m3_unified_value(float k, float eps) {
 VMF_HD float kl_m3_stable_value(float k) {
   const float e2 = fast_exp(-2.0f * k);
   const float rom = fast_rcp(1.0f - e2);
-  return fast_log(k * rom) + (0.69314718055994530942f - 1.0f) + 2.0f * k * e2 * rom;
+  return fast_log(k * rom) + (0.69314718055994530942f - 1.0f) + 2.0f * (k * e2) * rom;  // (k e2 first: 2k may overflow)
 }
 VMF_HD void kl_m3_eps_fast(float k, float eps, float* kl, float* g, bool finite_beyond = false) {
   if (k < 1.0f) {
@@ -289,7 +305,9 @@ VMF_HD void kl_m3_eps_fast(float k, float eps, float* kl, float* g, bool finite_
     const float ropq = fast_rcp(opq);
     *kl = (c1 - q) * ropq - l1p;
     const float sh = k * (1.0f + p);
-    *g = q * (2.0f + q) * (ropq * ropq * rk) + eps * sh * ropq * ropq * rk;
+    // (q / (1+q)) ((2+q) / (1+q)) / k: factors of at most 1 and 2, so a tiny kappa (q = eps / k up to 1e32) neither
+    // overflows q (2 + q) nor underflows 1 / (1+q)^2 on the way to the reference's 1 / kappa
+    *g = (q * ropq) * ((2.0f + q) * ropq) * rk + eps * sh * ropq * ropq * rk;
     return;
   }
   // (finite_beyond: the caller's form has no overflow to reproduce -- e^-k underflows to 0 and leaves log k + ln 2 - 1)
@@ -385,11 +403,14 @@ VMF_HD bool kl_value_fast(float kappa, int variant, float* kl_out, float* grad) 
       if (k < 1.0f) {
         if (!(k > 0.0f)) return false;
         kl_m3_eps_fast(k, 0.0f, &kl, &g);  // the cancellation-free small-k form
+      } else if (k > 3.0e38f) {  // +inf: the limit of log k + ln 2 - 1
+        kl = k;
+        g = 0.0f;
       } else {
         const float e2 = fast_exp(-2.0f * k);
         const float rom = fast_rcp(1.0f - e2);
         kl = kl_m3_stable_value(k);
-        g = fast_rcp(k) - k * (4.0f * e2 * rom * rom);
+        g = fast_rcp(k) - (k * e2) * (4.0f * rom * rom);
       }
     } break;
     case VMF_KL_STABLE_M2: {
@@ -398,7 +419,10 @@ VMF_HD bool kl_value_fast(float kappa, int variant, float* kl_out, float* grad) 
       // series k^2/4 - 3 k^4/64 + 5 k^6/576 - 77 k^8/49152 is exact to 2e-9 relative.
       if (kappa != kappa) return false;
       const float a = ::fabsf(kappa);
-      if (a < 0.25f) {
+      if (a > 1e19f) {  // 1 / a leaves the normal range on the way to the two series below: the leading terms of
+        kl = a > 3.0e38f ? a : kl_m2_value_f32(a);  // (log 2 pi k - 1) / 2 and of its slope 1 / 2k are exact to an ulp
+        g = 0.5f * fast_rcp(a);
+      } else if (a < 0.25f) {
         const float k2 = a * a;
         kl = k2 * (0.25f + k2 * (-3.0f / 64.0f + k2 * (5.0f / 576.0f + k2 * (-77.0f / 49152.0f))));
         g = a * (0.5f + k2 * (-3.0f / 16.0f + k2 * (5.0f / 96.0f + k2 * (-77.0f / 6144.0f))));

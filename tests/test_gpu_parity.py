@@ -1915,3 +1915,15 @@ def test_randomised_orders_and_arguments_of_ive_against_scipy():
     w = mod.sweep(40, 31, n_x=8000)["worst"]
     assert w["ive"][0] < 2e-12 and w["dive"][0] < 2e-12 and w["ratio"][0] < 3e-12 and w["log_ive"][0] < 1e-13, w
     assert w["ive32"][0] < 1.2e-7, w
+
+
+def test_randomised_sizes_views_and_values_of_the_kl_and_elbo_kernels():
+    """a short run of tests/fuzz_kl_elbo.py: random element counts and misaligned views, all six variants in both
+    dtypes, concentrations over eleven decades with 0 / negative / inf / NaN / huge values (NaN and inf positions
+    exact), fused sums, gradients, and the fused ELBO over random broadcast shapes (every case asserts in the sweep)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_kl_elbo", os.path.join(os.path.dirname(__file__), "fuzz_kl_elbo.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    w = mod.sweep(150, 41)["worst"]
+    assert w["kl64"] < 1e-12 and w["kl32"] < 2e-6 and w["elbo"] < 2e-6, w
