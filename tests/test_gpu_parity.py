@@ -1927,3 +1927,16 @@ def test_randomised_sizes_views_and_values_of_the_kl_and_elbo_kernels():
     spec.loader.exec_module(mod)
     w = mod.sweep(150, 41)["worst"]
     assert w["kl64"] < 1e-12 and w["kl32"] < 2e-6 and w["elbo"] < 2e-6, w
+
+
+def test_randomised_shapes_of_the_general_m_host_class():
+    """a short run of tests/fuzz_general_host.py: VonMisesFisher over random widths, batch / scale / sample shapes,
+    dtypes and raw means -- fused and separate log_prob against the oracle, entropy + KL = log area of the sphere, the
+    mean against scipy, and the moments of shared-mean draws against A_m(kappa) (every case asserts in the sweep)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_general_host",
+                                                  os.path.join(os.path.dirname(__file__), "fuzz_general_host.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    w = mod.sweep(120, 51)["worst"]
+    assert w["area"] < 1e-12 and w["mean"] < 1e-12 and w["moment_sigmas"] < 5.0, w
