@@ -174,7 +174,8 @@ VMF_KL_QUAD_M3(false, VMF_KL_STABLE_M3)
 
 template <typename T, int VEC, bool BESSEL, int VARIANT>
 __global__ __launch_bounds__(KL_BLOCK) void kl_fwd_kernel(const T* __restrict__ kappa, T* __restrict__ out,
-                                                          double* __restrict__ partial, int64_t n, KlBessel kb) {
+                                                          double* __restrict__ partial, int64_t n, KlBessel kb,
+                                                          double* __restrict__ direct_sum, double alpha) {
   constexpr int variant = VARIANT;
   constexpr int KL_UNROLL = kl_unroll(VARIANT);
   __shared__ double red[KL_BLOCK / 64];
@@ -210,7 +211,11 @@ __global__ __launch_bounds__(KL_BLOCK) void kl_fwd_kernel(const T* __restrict__ 
   }
   if (partial) {
     double t = block_sum_double(acc, red);
-    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    // a one-block launch (n up to a few thousand: the batch sizes of the models) is its own finish
+    if (threadIdx.x == 0) {
+      if (direct_sum) *direct_sum = alpha * t;
+      else partial[blockIdx.x] = t;
+    }
   }
 }
 
@@ -263,18 +268,20 @@ static int kl_fwd_launch(const char* who, const void* kappa, void* out, double* 
   VMF_REQUIRE(n == 0 || kappa, VMF_ERR_BAD_ARG, "%s: null kappa", who);
   KlBessel kb = make_kl_bessel();
   int grid = vmf_grid_for(dtype == VMF_F32 ? (n + 3) / 4 : n, KL_BLOCK, VMF_KL_WORKSPACE_DOUBLES);
+  // one block: the kernel writes alpha * sum itself (same bits as the finish over a single partial) -- one launch
+  double* const direct = (sum_out && n > 0 && grid == 1) ? sum_out : nullptr;
   if (n > 0) {
 #define VMF_KL_FWD(V)                                                                                                  \
   case V:                                                                                                              \
     if (dtype == VMF_F32 && ew_aligned16(kappa) && ew_aligned16(out))                                                  \
       hipLaunchKernelGGL((kl_fwd_kernel<float, 4, false, V>), dim3(grid), dim3(KL_BLOCK), 0, stream,                   \
-                         (const float*)kappa, (float*)out, sum_out ? workspace : nullptr, n, kb);                      \
+                         (const float*)kappa, (float*)out, sum_out ? workspace : nullptr, n, kb, direct, alpha);       \
     else if (dtype == VMF_F32)                                                                                         \
       hipLaunchKernelGGL((kl_fwd_kernel<float, 1, true, V>), dim3(grid), dim3(KL_BLOCK), 0, stream,                    \
-                         (const float*)kappa, (float*)out, sum_out ? workspace : nullptr, n, kb);                      \
+                         (const float*)kappa, (float*)out, sum_out ? workspace : nullptr, n, kb, direct, alpha);       \
     else                                                                                                               \
       hipLaunchKernelGGL((kl_fwd_kernel<double, 1, true, V>), dim3(grid), dim3(KL_BLOCK), 0, stream,                   \
-                         (const double*)kappa, (double*)out, sum_out ? workspace : nullptr, n, kb);                    \
+                         (const double*)kappa, (double*)out, sum_out ? workspace : nullptr, n, kb, direct, alpha);     \
     break
     // fp32 with 128-bit accesses: every variant has a single-precision form, so that instantiation leaves the
     // double-precision Bessel code out (46 instead of 149 VGPRs)
@@ -286,7 +293,7 @@ static int kl_fwd_launch(const char* who, const void* kappa, void* out, double* 
     int rc = vmf_check_launch(who);
     if (rc) return rc;
   }
-  if (sum_out) {
+  if (sum_out && !direct) {
     // every block of the first launch has written its partial; the finish reads exactly those `grid` words, so the
     // workspace needs no clearing whatever an earlier call left in it
     hipLaunchKernelGGL(kl_final_kernel, dim3(1), dim3(256), 0, stream, workspace, n > 0 ? grid : 0, alpha, sum_out);

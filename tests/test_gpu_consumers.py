@@ -216,6 +216,55 @@ def test_latent_loss_large_batch_vs_oracle_and_per_row(ds):
     np.testing.assert_allclose(N(mean), N(val), rtol=1e-14)
 
 
+@pytest.mark.parametrize("ds", list(DATASETS))
+@pytest.mark.parametrize("n_labels,rep", [(4099, 5), (1024, 4), (3, 333), (1, 1027), (257, 9)])
+def test_latent_loss_fp32_layouts_agree_with_fp64(ds, n_labels, rep):
+    """fp32 takes four rows per lane when z has three components and is 16-byte aligned, one row per lane otherwise:
+    both against the double-precision kernel on the same values -- row counts that are not multiples of four, label
+    counts that do (not) divide the quad, a view that starts mid-allocation, per-row output and gradient"""
+    gen = torch.Generator(device=DEV).manual_seed(n_labels)
+    n = n_labels * rep
+    base = torch.randn(n * 3 + 1, device=DEV, dtype=torch.float64, generator=gen)
+    labels64 = torch.rand(n_labels, 2, device=DEV, dtype=torch.float64, generator=gen) * 6.0
+    variant = list(DATASETS).index(ds)
+    lib, sp = _lib.lib(), _lib.stream_ptr(DEV)
+    ws = torch.empty(_lib.KL_WORKSPACE_DOUBLES, device=DEV, dtype=torch.float64)
+
+    def run(z, labels):
+        dt = _lib.dtype_code(z)
+        rows = torch.full((n,), float("nan"), device=DEV, dtype=z.dtype)
+        mean = torch.full((), float("nan"), device=DEV, dtype=z.dtype)
+        assert lib.vmf_latent_loss_fwd(_lib.ptr(z), _lib.ptr(labels), _lib.ptr(rows), _lib.ptr(mean), _lib.ptr(ws), n, 3,
+                                       n_labels, 2, variant, 1.5, 0.5, dt, sp) == 0
+        mean2 = torch.full((), float("nan"), device=DEV, dtype=z.dtype)
+        assert lib.vmf_latent_loss_fwd(_lib.ptr(z), _lib.ptr(labels), None, _lib.ptr(mean2), _lib.ptr(ws), n, 3,
+                                       n_labels, 2, variant, 1.5, 0.5, dt, sp) == 0
+        dz = torch.full((n, 3), float("nan"), device=DEV, dtype=z.dtype)
+        gm = torch.full((), 2.0, device=DEV, dtype=z.dtype)
+        assert lib.vmf_latent_loss_bwd(_lib.ptr(z), _lib.ptr(labels), _lib.ptr(gm), _lib.ptr(dz), n, 3, n_labels, 2,
+                                       variant, 1.5, 0.5, dt, sp) == 0
+        torch.cuda.synchronize()
+        assert N(mean).tobytes() == N(mean2).tobytes()
+        return N(rows).astype(np.float64), float(mean), N(dz).astype(np.float64)
+
+    for off in (0, 1):   # off = 1: the fp32 view is 4-byte aligned only -> one row per lane
+        z64 = base[off:off + 3 * n].view(n, 3)
+        if ds == "T2":
+            z64 = z64 * 0.3 + torch.tensor([1.2, 0.9, 0.0], device=DEV, dtype=torch.float64)
+        z32 = torch.empty(n * 3 + 4, device=DEV, dtype=torch.float32)[off:off + 3 * n].view(n, 3)
+        z32.copy_(z64)
+        l32 = labels64.float()
+        r64, m64, d64 = run(z32.double().contiguous(), l32.double())
+        r32, m32, d32 = run(z32, l32)
+        np.testing.assert_allclose(r32, r64, rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(m32, m64, rtol=1e-5)
+        # the gradient has poles (rho -> 0, |z_3| -> |z|): compare where it is tame
+        scale = np.abs(d64).max(axis=1, keepdims=True)
+        ok = (scale < 1e3 / n).repeat(3, axis=1)
+        np.testing.assert_allclose(d32[ok], d64[ok], rtol=2e-3, atol=1e-3 / n)
+        assert np.isfinite(d32).all() == np.isfinite(d64).all()
+
+
 def test_latent_loss_errors_and_empty():
     z = torch.randn(4, 3, device=DEV)
     lab = torch.rand(4, 2, device=DEV)

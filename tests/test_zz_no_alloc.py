@@ -45,8 +45,9 @@ def _both(kappa, variant, with_out):
 def test_static_scratch_kl_matches_workspace_kl_two_calls_in_a_row(dtype, variant):
     g = torch.Generator(device=DEV).manual_seed(3)
     big = torch.exp(torch.rand((1 << 21) + 13, device=DEV, generator=g, dtype=torch.float64) * np.log(80.0)).to(dtype)
-    small = big[: 1000 + 3].clone() * 0.5   # fewer blocks than the first call: most of the array keeps old partials
-    for kappa in (big, small):
+    small = big[: 5000 + 3].clone() * 0.5   # fewer blocks than the first call: most of the array keeps old partials
+    tiny = big[: 300 + 1].clone() * 0.25    # one block: the kernel writes the sum itself and no partial is stored
+    for kappa in (big, small, tiny):
         for with_out in (False, True):
             (s_ws, o_ws), (s_st, o_st) = _both(kappa, variant, with_out)
             assert np.isfinite(s_ws).all()
