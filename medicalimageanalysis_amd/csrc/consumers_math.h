@@ -50,6 +50,10 @@ template <> struct MT<float> {
   static VMF_HD float atan2(float y, float x) { return ::atan2f(y, x); }
 #endif
   static VMF_HD float fmod(float a, float b) { return ::fmodf(a, b); }
+  // quotients and roots through the 1-ulp hardware reciprocal / square root (the IEEE sequences cost ~10 instructions
+  // each, and a row's gradient has eight quotients)
+  static VMF_HD float div(float a, float b) { return a * fast_rcp(b); }
+  static VMF_HD float sqrt(float x) { return fast_sqrt(x); }
 };
 template <> struct MT<double> {
   static VMF_HD double sin(double x) { return ::sin(x); }
@@ -57,6 +61,8 @@ template <> struct MT<double> {
   static VMF_HD double acos(double x) { return ::acos(x); }
   static VMF_HD double atan2(double y, double x) { return ::atan2(y, x); }
   static VMF_HD double fmod(double a, double b) { return ::fmod(a, b); }
+  static VMF_HD double div(double a, double b) { return a / b; }
+  static VMF_HD double sqrt(double x) { return ::sqrt(x); }
 };
 
 // (phi + 2 pi) % (2 pi) as torch evaluates it: the Python scalar 2*pi is rounded to the tensor's dtype, and
@@ -105,9 +111,9 @@ VMF_HD T latent_loss_s1(const T* z, int zdim, T gt_phi, T* dz) {
   T om = (T)1 - d;
   if (GRAD) {
     T dphi = (T)2 * om * MT<T>::sin(a);
-    T rho2 = x * x + y * y;
-    dz[0] = dphi * (-y / rho2);
-    dz[1] = dphi * (x / rho2);
+    T q = MT<T>::div(dphi, x * x + y * y);
+    dz[0] = -y * q;
+    dz[1] = x * q;
     for (int c = 2; c < zdim; ++c) dz[c] = (T)0;
   }
   return om * om;                                      // :122
@@ -117,9 +123,9 @@ template <typename T, bool GRAD>
 VMF_HD T latent_loss_s2(const T* z, int zdim, T theta_gt, T phi_gt, T* dz) {
   T ss = (T)0;
   for (int c = 0; c < zdim; ++c) ss += z[c] * z[c];
-  const T nrm = M<T>::sqrt(ss);                        // :134
+  const T nrm = MT<T>::sqrt(ss);                       // :134
   const T x = z[0], y = z[1];
-  const T raw = z[2] / nrm;
+  const T raw = MT<T>::div(z[2], nrm);
   const T zc = raw < (T)-1 ? (T)-1 : (raw > (T)1 ? (T)1 : raw);   // :138
   const T theta_hat = MT<T>::acos(zc);                 // :140
   const T phi_hat = wrap_2pi<T>(MT<T>::atan2(y, x));   // :141-142
@@ -134,13 +140,14 @@ VMF_HD T latent_loss_s2(const T* z, int zdim, T theta_gt, T phi_gt, T* dz) {
     const T d_theta_hat = dl * (-MT<T>::sin(dth) + sgt * MT<T>::cos(theta_hat) * omc);
     const T d_phi_hat = dl * (-(sgt * sth * MT<T>::sin(dph)));
     // acos' = -1/sqrt(1-c^2); clamp passes the gradient only inside [-1, 1]
-    const T d_raw = (raw >= (T)-1 && raw <= (T)1) ? -d_theta_hat / M<T>::sqrt((T)1 - zc * zc) : (T)0;
-    const T rho2 = x * x + y * y;
-    const T n3 = nrm * nrm * nrm;
-    for (int c = 0; c < zdim; ++c) dz[c] = -d_raw * z[2] * z[c] / n3;
-    dz[2] += d_raw / nrm;
-    dz[0] += d_phi_hat * (-y / rho2);
-    dz[1] += d_phi_hat * (x / rho2);
+    const T d_raw = (raw >= (T)-1 && raw <= (T)1) ? MT<T>::div(-d_theta_hat, MT<T>::sqrt((T)1 - zc * zc)) : (T)0;
+    const T qphi = MT<T>::div(d_phi_hat, x * x + y * y);
+    const T rn = MT<T>::div(d_raw, nrm);              // d raw / |z|
+    const T k3 = MT<T>::div(-rn * z[2], ss);          // -d raw z_3 / |z|^3
+    for (int c = 0; c < zdim; ++c) dz[c] = k3 * z[c];
+    dz[2] += rn;
+    dz[0] -= y * qphi;
+    dz[1] += x * qphi;
   }
   return s * s;                                        // :149
 }
@@ -148,7 +155,7 @@ VMF_HD T latent_loss_s2(const T* z, int zdim, T theta_gt, T phi_gt, T* dz) {
 template <typename T, bool GRAD>
 VMF_HD T latent_loss_t2(const T* z, int zdim, T l_theta, T l_phi, T R, T r, T* dz) {
   const T x = z[0], y = z[1], zc = z[2];
-  const T rho = M<T>::sqrt(x * x + y * y);             // :162
+  const T rho = MT<T>::sqrt(x * x + y * y);            // :162
   const T s = rho - R;
   const T phi = wrap_2pi<T>(MT<T>::atan2(y, x));       // :164,168
   const T theta = wrap_2pi<T>(MT<T>::atan2(zc, s));    // :165,169
@@ -158,12 +165,12 @@ VMF_HD T latent_loss_t2(const T* z, int zdim, T l_theta, T l_phi, T R, T r, T* d
   const T val = ((T)1 - MT<T>::cos(a)) + ((T)1 - MT<T>::cos(b)) + (T)0.1 * (q * q);
   if (GRAD) {
     const T d_theta = MT<T>::sin(a), d_phi = MT<T>::sin(b), d_q = (T)0.2 * q;
-    const T h2 = s * s + zc * zc;
-    const T d_s = d_theta * (-zc / h2) + d_q * (T)2 * s;
-    const T d_zc = d_theta * (s / h2) + d_q * (T)2 * zc;
-    const T rho2 = rho * rho;
-    dz[0] = d_s * (x / rho) + d_phi * (-y / rho2);
-    dz[1] = d_s * (y / rho) + d_phi * (x / rho2);
+    const T qth = MT<T>::div(d_theta, s * s + zc * zc);
+    const T d_s = -zc * qth + d_q * (T)2 * s;
+    const T d_zc = s * qth + d_q * (T)2 * zc;
+    const T qs = MT<T>::div(d_s, rho), qphi = MT<T>::div(d_phi, rho * rho);
+    dz[0] = x * qs - y * qphi;
+    dz[1] = y * qs + x * qphi;
     dz[2] = d_zc;
     for (int c = 3; c < zdim; ++c) dz[c] = (T)0;
   }
