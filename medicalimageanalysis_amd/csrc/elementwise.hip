@@ -268,6 +268,8 @@ static int kl_fwd_launch(const char* who, const void* kappa, void* out, double* 
   VMF_REQUIRE(n == 0 || kappa, VMF_ERR_BAD_ARG, "%s: null kappa", who);
   KlBessel kb = make_kl_bessel();
   int grid = vmf_grid_for(dtype == VMF_F32 ? (n + 3) / 4 : n, KL_BLOCK, VMF_KL_WORKSPACE_DOUBLES);
+  // what one block covers in a single trip of its loop stays one block (batch-sized inputs: no second launch, below)
+  if (dtype == VMF_F32 && sum_out && (n + 3) / 4 <= (int64_t)KL_BLOCK * kl_unroll(variant)) grid = 1;
   // one block: the kernel writes alpha * sum itself (same bits as the finish over a single partial) -- one launch
   double* const direct = (sum_out && n > 0 && grid == 1) ? sum_out : nullptr;
   if (n > 0) {

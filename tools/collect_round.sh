@@ -16,6 +16,7 @@ run 200 python3 tools/bench_vmf3.py > $out/${tag}_bench_vmf3.md
 run 200 python3 tools/bench_kl.py > $out/${tag}_bench_kl.md
 run 300 python3 tools/bench_narrow.py > $out/${tag}_bench_narrow.md
 run 400 python3 tools/bench_extra.py > $out/${tag}_bench_extra.md
+run 120 python3 tools/bench_latent.py > $out/${tag}_bench_latent.md
 run 100 python3 tools/count_launches.py > $out/${tag}_launches.md
 run 300 bash tools/profile_vmf3.sh ${tag}_vmf3
 cd /tmp && export TMPDIR=/tmp

@@ -15,7 +15,7 @@ python3 tools/summarise_profiles.py pmcall $g/pmc_${tag}_kl_fetch $g/pmc_${tag}_
 for c in 1 2 4 5; do cp $g/${tag}_bench_cfg$c.json profiles/${name}_bench_cfg$c.json; done
 cp $g/${tag}_bench_default.json profiles/${name}_bench_final.json
 grep '^{' $g/bench_$tag.json > profiles/${name}_bench_final_profiled.json
-for t in vmf3 kl narrow extra; do cp $g/${tag}_bench_$t.md profiles/${name}_bench_$t.md; done
+for t in vmf3 kl narrow extra latent; do cp $g/${tag}_bench_$t.md profiles/${name}_bench_$t.md; done
 cp $g/${tag}_launches.md profiles/${name}_launches_per_step.md
 [ -f $g/parity_margins.json ] && cp $g/parity_margins.json profiles/${name}_parity_margins.json
 echo published
