@@ -508,8 +508,11 @@ VMF_HD float kl_eval<float, false>(float kappa, int variant, const KlBessel& kb,
 }
 
 // value alone (forward kernels): the compiler drops the derivative of the forms above by itself; the two S^1 variants
-// take their own value-only fits.  VMF_KL_S1_I0I1 keeps the reference's overflow behaviour (NaN once I0 leaves the
-// float range, kappa > ~91.9) through the value-and-derivative form beyond 85.
+// take their own value-only fits.  VMF_KL_S1_I0I1 keeps the reference's overflow behaviour (NaN once e^kappa leaves the
+// float range, kappa > 88.7228): the fit below 88.70, NaN from 88.75 on, and the value-and-derivative form -- which
+// forms e^kappa and so decides the overflow itself -- only in the window between them.  (With that form for everything
+// beyond 85, a batch with a third of its concentrations past the overflow point ran every wave through all three
+// chains: 0.37 ms per 2^27 against 0.17 for concentrations below 80.)
 template <typename T, bool BESSEL>
 VMF_HD T kl_eval_value(T kappa, int variant, const KlBessel& kb) {
   T g;
@@ -519,8 +522,9 @@ VMF_HD T kl_eval_value(T kappa, int variant, const KlBessel& kb) {
   template <>                                                                                                 \
   VMF_HD float kl_eval_value<float, BESSEL>(float kappa, int variant, const KlBessel& kb) {                   \
     const float a = ::fabsf(kappa);                                                                           \
-    if ((variant == VMF_KL_STABLE_M2 && a <= 3.0e38f) || (variant == VMF_KL_S1_I0I1 && a <= 85.0f))           \
+    if ((variant == VMF_KL_STABLE_M2 && a <= 3.0e38f) || (variant == VMF_KL_S1_I0I1 && a <= 88.70f))          \
       return kl_m2_value_f32(a);                                                                              \
+    if (variant == VMF_KL_S1_I0I1 && a >= 88.75f) return NAN; /* e^a = inf: inf / inf in the reference */     \
     float g;                                                                                                  \
     return kl_eval<float, BESSEL>(kappa, variant, kb, &g);                                                    \
   }
