@@ -149,11 +149,26 @@ __device__ __forceinline__ void kl_eval_value4(const T (&k)[4], T (&o)[4], const
 template <int VARIANT>
 __device__ __forceinline__ bool kl_quad_m3(const float (&k)[4], float (&o)[4]) {
   constexpr float hi_limit = VARIANT == VMF_KL_SPHERICAL_PIECEWISE ? 1000.0f
-                             : (VARIANT == VMF_KL_STABLE_M3 ? 3.0e38f : 85.0f);
+                             : (VARIANT == VMF_KL_STABLE_M3 ? 3.0e38f : KL_M3_UNIFIED_MAX);
   constexpr float eps = VARIANT == VMF_KL_SPHERICAL_PIECEWISE ? 1e-8f : (VARIANT == VMF_KL_CIRCULAR_EPS ? 1e-6f : 0.0f);
   const float lo = fminf(fminf(k[0], k[1]), fminf(k[2], k[3])), hi = fmaxf(fmaxf(k[0], k[1]), fmaxf(k[2], k[3]));
   // fminf / fmaxf drop a NaN operand: the sum test catches it
-  if (!(lo >= 1.0f && hi <= hi_limit) || (k[0] + k[1] + k[2] + k[3]) != (k[0] + k[1] + k[2] + k[3])) return false;
+  const bool in_range = lo >= 1.0f && hi <= hi_limit && (k[0] + k[1] + k[2] + k[3]) == (k[0] + k[1] + k[2] + k[3]);
+  constexpr bool OVERFLOWS = VARIANT == VMF_KL_TORUS_RAW || VARIANT == VMF_KL_CIRCULAR_EPS;
+  // (the vote keeps a wave on ONE of the two straight-line paths: lanes split between them would run both in turn)
+  if (OVERFLOWS ? !__all(in_range) : !in_range) {
+    // torus / circular forms: concentrations past sinh's overflow point are NaN in the reference; a quad that holds
+    // some (a batch with kappa up to 1e3 has them in every wave) still takes the straight-line form -- with the
+    // per-element form instead, such a batch ran at 0.26 ms per 2^27 against 0.12
+    if (!OVERFLOWS) return false;
+    bool ok = true;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) ok = ok && k[x] >= 1.0f && (k[x] <= KL_M3_UNIFIED_MAX || k[x] >= KL_M3_NAN_MIN);
+    if (!ok) return false;  // (a NaN fails k >= 1)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) o[x] = k[x] >= KL_M3_NAN_MIN ? NAN : kl_m3_unified_value(k[x], eps);
+    return true;
+  }
 #pragma unroll
   for (int x = 0; x < 4; ++x)
     o[x] = VARIANT == VMF_KL_STABLE_M3 ? kl_m3_stable_value(k[x]) : kl_m3_unified_value(k[x], eps);

@@ -293,6 +293,10 @@ VMF_HD float kl_m3_stable_value(float k) {
   const float rom = fast_rcp(1.0f - e2);
   return fast_log(k * rom) + (0.69314718055994530942f - 1.0f) + 2.0f * (k * e2) * rom;  // (k e2 first: 2k may overflow)
 }
+// The reference's forms hold sinh k: finite up to sinhf's overflow point 89.416, inf / inf = NaN beyond.  The straight-line
+// form serves everything up to KL_M3_UNIFIED_MAX, the value is NaN from KL_M3_NAN_MIN on, and only the window between
+// them is left to the form that builds sinh k and so decides the overflow itself.
+constexpr float KL_M3_UNIFIED_MAX = 89.40f, KL_M3_NAN_MIN = 89.42f;
 VMF_HD void kl_m3_eps_fast(float k, float eps, float* kl, float* g, bool finite_beyond = false) {
   if (k < 1.0f) {
     const float k2 = k * k;
@@ -311,8 +315,8 @@ VMF_HD void kl_m3_eps_fast(float k, float eps, float* kl, float* g, bool finite_
     return;
   }
   // (finite_beyond: the caller's form has no overflow to reproduce -- e^-k underflows to 0 and leaves log k + ln 2 - 1)
-  if (k <= 85.0f || finite_beyond) {
-    // 1 <= k <= 85: everything through em = e^-k (one exponential, nothing overflows, nothing cancels).  With
+  if (k <= KL_M3_UNIFIED_MAX || finite_beyond) {
+    // 1 <= k <= 89.40, just below sinhf's overflow point 89.416: everything through em = e^-k (one exponential, nothing overflows, nothing cancels).  With
     // D = 1 - e^-2k + 2 eps e^-k:  sinh k + eps = D e^k / 2,  cosh k / (sinh k + eps) = (1 + e^-2k) / D, so
     //   kl = log k + (ln 2 - 1) - log D + 2 k (e^-2k - eps e^-k) / D
     //   d/dk = 1/k + k (2 eps e^-k (1 - e^-2k) - 4 e^-2k) / D^2

@@ -17,7 +17,7 @@ n = 1 << 27
 g = torch.Generator(device=DEV).manual_seed(0)
 for hi in (80.0, 1e3):
     kap = torch.exp(torch.rand(n, device=DEV, generator=g) * np.log(hi))
-    for variant in ("s1", "stable_m2"):
+    for variant in ("s1", "stable_m2", "spherical", "torus", "circular", "stable_m3"):
         for _ in range(10):
             klmod.kl_sum(kap, variant)
         torch.cuda.synchronize()
