@@ -139,8 +139,8 @@ __device__ __forceinline__ double sum4_to_double(const T (&v)[4]) {
 // Four consecutive elements.  The m = 3 variants in single precision have one straight-line form on the range an
 // encoder produces (kappa = softplus + 1 >= 1, below the point where the variant's own overflow behaviour starts): one
 // range check per four elements instead of the per-element region branches (spherical 27 -> 19 instructions per element);
-// a quad with any element outside the range -- or NaN -- takes the per-element form.  Same bits either way: both call
-// the same functions.
+// a quad with any element outside the range -- or NaN -- takes the per-element form.  Both call the same functions
+// (the two inlined copies may differ in the last bit: the compiler contracts them separately).
 template <typename T, bool BESSEL, int VARIANT>
 __device__ __forceinline__ void kl_eval_value4(const T (&k)[4], T (&o)[4], const KlBessel& kb) {
 #pragma unroll

@@ -471,6 +471,40 @@ def test_kl_fp32_fast_path_dense_grid(oracle, name):
         assert abs(s - r64[lo:hi].sum()) <= 2e-5 * abs(r64[lo:hi].sum()) + 1e-7 * (hi - lo) + 1e-6
 
 
+@pytest.mark.parametrize("name", ["torus", "circular", "s1", "spherical", "stable_m3", "stable_m2"])
+def test_kl_fp32_value_does_not_depend_on_neighbours(oracle, name):
+    """The fused fp32 forward picks a form per group of four elements (and, for the forms that overflow in the
+    reference, per wave): concentrations below 1, in range, in the window around the overflow point, beyond it, and
+    infinite, sorted (homogeneous groups) and shuffled (every group and wave mixed), must give the same value per element;
+    NaN exactly where the reference's expression overflows; the sum of the finite part against the oracle"""
+    gen = np.random.default_rng(17)
+    parts = [np.exp(gen.uniform(np.log(1e-2), 0.0, 3000)), np.exp(gen.uniform(0.0, np.log(85.0), 20000)),
+             gen.uniform(85.0, 88.6, 3000), gen.uniform(88.6, 89.5, 3000), np.exp(gen.uniform(np.log(89.5), np.log(1e4), 6000)),
+             np.array([np.inf, 88.70, 88.75, 89.40, 89.42, 1.0, 85.0])]
+    k_sorted = np.sort(np.concatenate(parts)).astype(np.float32)
+    perm = gen.permutation(k_sorted.size)
+    k_shuf = k_sorted[perm]
+    o_sorted = N(klmod.kl_per_sample(T(k_sorted), name))
+    o_shuf = N(klmod.kl_per_sample(T(k_shuf), name))
+    np.testing.assert_array_equal(np.isnan(o_shuf), np.isnan(o_sorted[perm]))
+    fin = ~np.isnan(o_shuf)
+    # (the same formulas on every path; the compiler contracts the inlined copies differently: an ulp or two)
+    np.testing.assert_allclose(o_shuf[fin], o_sorted[perm][fin], rtol=1e-6, atol=1e-7)
+    kk = k_sorted.astype(np.float64)
+    if name in ("torus", "circular"):
+        assert np.isnan(o_sorted[kk >= 89.42]).all() and np.isfinite(o_sorted[kk <= 89.40]).all()
+    elif name == "s1":
+        assert np.isnan(o_sorted[kk >= 88.75]).all() and np.isfinite(o_sorted[kk <= 88.70]).all()
+    else:  # (the spherical form is inf - inf at an infinite concentration, in the reference too)
+        assert not np.isnan(o_sorted[np.isfinite(kk)]).any()
+    ok = np.isfinite(o_sorted) & np.isfinite(kk)
+    r64, _, _ = oracle.vmf_kl(np.ascontiguousarray(kk[ok]), klmod.VARIANTS[name])
+    # (beyond 1000 the spherical form keeps the reference's fp32 operation order, rounding of k - k included)
+    np.testing.assert_allclose(o_sorted[ok], r64, rtol=1e-4 if name == "spherical" else 3e-5, atol=3e-6)
+    got = float(klmod.kl_sum(T(np.ascontiguousarray(k_shuf[np.isfinite(o_shuf) & np.isfinite(k_shuf)])), name))
+    assert abs(got - r64.sum()) <= 2e-5 * abs(r64.sum())
+
+
 def test_kl_large_reduction_matches_oracle(oracle):
     gen = np.random.default_rng(3)
     k = np.exp(gen.uniform(0, np.log(100.0), 1 << 20)).astype(np.float32)
