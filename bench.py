@@ -635,6 +635,7 @@ def run_rank(a):
                                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                                "kernel": wl.kernel, "kernel_ms": kern_ms, "kernel_ms_min": float(np.min(kern_all)),
                                "kernel_ms_median": float(np.median(kern_all)),
+                               "kernel_ms_each": [round(float(t), 4) for t in kern_all],
                                "achieved_at_median": nbytes / (float(np.median(kern_all)) * 1e-3) / 1e9,
                                "bytes_per_unit": wl.bytes_per_unit, "bytes_per_launch": nbytes,
                                "device_copy_GBps": copy, "frac_of_device_copy": achieved / copy if copy else None}
