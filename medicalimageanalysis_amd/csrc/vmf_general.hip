@@ -19,6 +19,9 @@
 #include "vmf_math.h"
 
 // build-time tuning knobs (defaults are the measured optimum on MI355X for m = 64 fp32)
+#ifndef VMF_PK_SUMS
+#define VMF_PK_SUMS 1
+#endif
 #ifndef VMF_TILE_ROWS
 #define VMF_TILE_ROWS 128
 #endif
@@ -324,7 +327,9 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
           }
           if (k + 1 >= p.max_prop) acc = true;  // the last proposal allowed is taken regardless
           if (acc) {
-            T parked = c2;  // (1 - w)(1 + w), formed where 1 + w is known without cancellation
+            // sqrt((1 - w)(1 + w)) -- 1 + w taken where it is known without cancellation -- is what phase 2 multiplies
+            // by: the root is taken here, once per row, instead of by every lane of the row's group at every step
+            T parked = F<T>::sqrt(c2 < (T)1e-10 ? (T)1e-10 : c2);
             if (LPR == 1 && circle) {
               parked = circle_pack((T)2 * b * pc, (T)2 * ps, neg);
               T opw;
@@ -360,18 +365,22 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
     const T* const ga_t = (!FAST && !CIRCLE && p.gauss) ? p.gauss + tile0 * m : nullptr;
     // fp32 streaming mode keeps the NEXT step's mu rows in flight while the current step computes and stores.
     constexpr bool PF = FAST && sizeof(T) == 4;
-    f32x4 pf[P], cur[P];
+    // ONE register set: a step copies it into its own mu registers first, so the next rows can land in it while the
+    // step computes (a second set, copied over after the wait, cost four more 64-bit moves per step)
+    f32x4 cur[P];
     if (PF && ntile > 0) {
       const int rr0 = grp < ntile ? grp : 0;
 #pragma unroll
       for (int j = 0; j < P; ++j)
-        prefetch_issue(pf[j], reinterpret_cast<const float*>(mu_t + rr0 * p.mu_stride + 4 * (j * LPR + sub)));
+        prefetch_issue(cur[j], reinterpret_cast<const float*>(mu_t + rr0 * p.mu_stride + 4 * (j * LPR + sub)));
 #pragma unroll
-      for (int j = 0; j < P; ++j) prefetch_wait(pf[j]);
-#pragma unroll
-      for (int j = 0; j < P; ++j) cur[j] = pf[j];
+      for (int j = 0; j < P; ++j) prefetch_wait(cur[j]);
     }
     const T gmask0 = sub == 0 ? (T)0 : (T)1;
+    // element offset of the prefetched row inside the tile, advanced by addition (the product row * stride per step
+    // is a quarter-rate instruction)
+    int pf_off = (grp + RPI) * p.mu_stride;
+    const int pf_step = RPI * p.mu_stride;
     for (int r0 = 0; r0 < ntile; r0 += RPI) {
       const int r = r0 + grp;
       const bool valid = r < ntile;
@@ -385,10 +394,11 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
           mu[j][0] = (T)cur[j].x; mu[j][1] = (T)cur[j].y; mu[j][2] = (T)cur[j].z; mu[j][3] = (T)cur[j].w;
         }
         if (more) {
-          const int rn = r + RPI < ntile ? r + RPI : 0;
+          const int offn = r + RPI < ntile ? pf_off : 0;
 #pragma unroll
           for (int j = 0; j < P; ++j)
-            prefetch_issue(pf[j], reinterpret_cast<const float*>(mu_t + rn * p.mu_stride + 4 * (j * LPR + sub)));
+            prefetch_issue(cur[j], reinterpret_cast<const float*>(mu_t + (uint32_t)offn + 4 * (j * LPR + sub)));
+          pf_off += pf_step;
         }
       } else if (FAST) {
 #pragma unroll
@@ -421,7 +431,7 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
             noise4<T, VEC>(ga_t ? ga_t + (int64_t)rr * m : nullptr, grow0 + (uint64_t)rr, chunk, m, key, g[j]);
           }
         }
-        if (FAST && sizeof(T) == 4) {
+        if (VMF_PK_SUMS && FAST && sizeof(T) == 4) {
           // the three partial sums in packed pairs (v_pk_mul / v_pk_fma: two lanes of arithmetic per instruction)
           const f32x2 ga = {(float)g[j][0], (float)g[j][1]}, gb = {(float)g[j][2], (float)g[j][3]};
           const f32x2 ma = {(float)mu[j][0], (float)mu[j][1]}, mb = {(float)mu[j][2], (float)mu[j][3]};
@@ -440,7 +450,7 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
           }
         }
       }
-      if (FAST && sizeof(T) == 4) {
+      if (VMF_PK_SUMS && FAST && sizeof(T) == 4) {
         gg = (T)(gg2.x + gg2.y); dd = (T)(dd2.x + dd2.y); gm = (T)(gm2.x + gm2.y);
       }
       group_allreduce_sum3<LPR, T>(gg, dd, gm);
@@ -454,26 +464,24 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
       const T d0 = (T)1 - mu0;
       const T tail = dd * (inv * inv);  // |mu|^2 without its first element
       dd = d0 * d0 + tail;              // |e1 - mu|^2
-      T w, c2;  // w, 1 - w^2
+      T w, sc2;  // w, sqrt(1 - w^2)
       if (LPR == 1 && circle) {
         T omw, opw;
         circle_unpack(somw[rr], &w, &omw, &opw);
-        c2 = omw * opw;
+        const T c2 = omw * opw;
+        sc2 = F<T>::sqrt(c2 < (T)1e-10 ? (T)1e-10 : c2);
       } else {
-        c2 = somw[rr];
+        sc2 = somw[rr];
         w = sw[rr];
       }
-      c2 = c2 < (T)1e-10 ? (T)1e-10 : c2;
-      const T f = F<T>::sqrt(c2) * F<T>::rsqrt(gg);
+      const T f = sc2 * F<T>::rsqrt(gg);
       const T zd = w * d0 - f * gm;
       const T coef = dd > (T)1e-30 ? (T)2 * zd * F<T>::rcp(dd) : (T)0;
       const T coef_mu = coef * inv;
       // retire the prefetch of the next rows BEFORE this step's store is issued (see prefetch_issue)
       if (PF && more) {
 #pragma unroll
-        for (int jj = 0; jj < P; ++jj) prefetch_wait(pf[jj]);
-#pragma unroll
-        for (int jj = 0; jj < P; ++jj) cur[jj] = pf[jj];
+        for (int jj = 0; jj < P; ++jj) prefetch_wait(cur[jj]);
       }
       if (valid) {
         T* zrow = z_t + rr * m;
