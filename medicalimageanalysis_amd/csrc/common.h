@@ -120,6 +120,11 @@ struct U4 {
 #ifndef VMF_PHILOX_ROUNDS
 #define VMF_PHILOX_ROUNDS 10
 #endif
+// a ^ b ^ c in one instruction (gfx950's three-input bit operation, truth table 0x96): a Philox round is two wide
+// multiplies and two such folds instead of four two-input ones -- 58 -> 39 instructions per call
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
 __device__ __forceinline__ U4 philox4x32_10(uint64_t index, uint32_t slot, PhiloxKey key) {
   uint32_t c0 = (uint32_t)index, c1 = (uint32_t)(index >> 32), c2 = slot, c3 = key.c3;
   uint32_t k0 = key.k0, k1 = key.k1;
@@ -127,9 +132,9 @@ __device__ __forceinline__ U4 philox4x32_10(uint64_t index, uint32_t slot, Philo
   for (int r = 0; r < VMF_PHILOX_ROUNDS; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
     uint32_t n1 = (uint32_t)p1;
-    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
     uint32_t n3 = (uint32_t)p0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += 0x9E3779B9u;
