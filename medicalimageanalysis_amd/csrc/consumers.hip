@@ -442,7 +442,7 @@ static inline int ll_tile_grid(int64_t n, int max_blocks) {
   return vmf_grid_for((n + LL_TILE - 1) / LL_TILE, LL_BLOCK / 64, max_blocks);
 }
 
-static inline bool ll_quad_ok(int dtype, int zdim, const void* z, const void* a, const void* b) {
+static inline bool ll_tile_ok(int dtype, int zdim, const void* z, const void* a, const void* b) {
   return dtype == VMF_F32 && zdim == 3 && aligned16(z) && aligned16(a) && aligned16(b);
 }
 
@@ -467,7 +467,7 @@ extern "C" int vmf_latent_loss_fwd(const void* z, const void* labels, void* per_
   VMF_REQUIRE(dtype == VMF_F32 || dtype == VMF_F64, VMF_ERR_DTYPE, "dtype %d", dtype);
   VMF_REQUIRE(mean_out && workspace && labels && (n == 0 || z), VMF_ERR_BAD_ARG, "vmf_latent_loss_fwd: null pointer");
   int grid = vmf_grid_for(n, 256, VMF_KL_WORKSPACE_DOUBLES);
-  if (n > 0 && ll_quad_ok(dtype, zdim, z, per_row_out, nullptr)) {
+  if (n > 0 && ll_tile_ok(dtype, zdim, z, per_row_out, nullptr)) {
     grid = ll_tile_grid(n, VMF_KL_WORKSPACE_DOUBLES);
     const bool direct = grid == 1;
     hipLaunchKernelGGL(latent_loss_tile_kernel<false>, dim3(grid), dim3(LL_BLOCK), 0, (hipStream_t)stream,
@@ -500,7 +500,7 @@ extern "C" int vmf_latent_loss_bwd(const void* z, const void* labels, const void
   if (rc) return rc;
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(z && labels && grad_mean && dz, VMF_ERR_BAD_ARG, "vmf_latent_loss_bwd: null pointer");
-  if (ll_quad_ok(dtype, zdim, z, dz, nullptr)) {
+  if (ll_tile_ok(dtype, zdim, z, dz, nullptr)) {
     hipLaunchKernelGGL(latent_loss_tile_kernel<true>, dim3(ll_tile_grid(n, 256 * 8)), dim3(LL_BLOCK), 0,
                        (hipStream_t)stream, (const float*)z, (const float*)labels, (float*)nullptr, (double*)nullptr,
                        (const float*)grad_mean, (float)(1.0 / (double)n), (float*)dz, n, n_labels, label_cols, variant,
