@@ -411,7 +411,7 @@ class TorusAndS1:
         self.seed, self.row0 = 0x5EED, rank * n
         self.units, self.dtype, self.unit = n, "f32", "circle draws/s"
         self.bytes_per_unit = 20
-        self.kernel = "vmf_rsample_fwd_kernel (m=2)"
+        self.kernel = "vmf_circle_fwd_kernel"
         self.metric = f"T^16 von Mises draws/sec ({self.rows} rows x 16 circles per GPU) + S^1-VAE sampler and KL"
         self.workload = (f"product of 16 von Mises circles: vMF m=2 rsample over {n} (mu,kappa) pairs per GPU, kappa "
                          f"log-uniform [1,1e3], then the S^1-VAE projected-normal sampler and the sum of kappa I1/I0 - log I0 "

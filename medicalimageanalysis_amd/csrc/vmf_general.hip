@@ -39,8 +39,8 @@ constexpr int WAVES = VMF_WAVES;
 #endif
 // Rows per tile.  The rejection phase ends with a tail in which the last few rows of the tile wait for their
 // acceptance on a mostly idle wave; its cost is per tile, so narrow rows, whose phase 2 is short, take larger tiles:
-// 384 rows for m <= 4 (one lane per row) and 320 for m <= 16; the circle instantiation, with a single slab, 1024
-// (2^27 rows: 0.90 ms with 512-row tiles, 0.82 with 1024, 1.06 with 2048).  Measured on 2^27 / 2^24 rows against
+// 384 rows for m <= 4 (one lane per row) and 320 for m <= 16; the one-row-per-lane circle instantiation 512 (dense
+// aligned fp32 circles take vmf_circle_fwd_kernel instead).  Measured on 2^27 / 2^24 rows against
 // 128-row tiles: m = 2 1.66 -> 1.22 ms, m = 3 0.259 -> 0.211, m = 4 0.220 -> 0.179, m = 8 .. 16 -4 .. -10 %.  512-row tiles are
 // slower again (the LDS slabs then limit the resident waves), and walking several 128-row tiles per wave was 10-20 %
 // slower than one (more waves in flight beat fewer wave launches).
@@ -51,7 +51,7 @@ constexpr int WAVES = VMF_WAVES;
 #define VMF_TILE_ROWS_NARROW 320
 #endif
 #ifndef VMF_TILE_ROWS_CIRCLE
-#define VMF_TILE_ROWS_CIRCLE 1024
+#define VMF_TILE_ROWS_CIRCLE 512
 #endif
 // Wide rows: the tile shrinks with the row so that a wave's footprint stays near VMF_TILE_ELEMS elements of mu and
 // of z (32 KiB each in fp32, what 128 rows of m = 64 are), but not below VMF_TILE_ROWS_MIN rows.  Against 128-row
@@ -234,11 +234,9 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
   constexpr bool FAST = MODE == 2;
   constexpr bool CIRCLE = MODE == 3;
   const PhiloxKey key = philox_resolve(p.ka);  // scalar: seed + host offset (+ device-resident offset)
-  // the circle instantiation parks one word per row (see circle_pack), so its tiles can be
-  // larger in the same LDS footprint
   constexpr int TILE_ROWS = CIRCLE ? VMF_TILE_ROWS_CIRCLE : tile_rows(LPR, P);
   // one array for both slabs, so that phase 2 fetches a row's w and 1 - w^2 with a single two-address LDS read
-  __shared__ T s_wc[WAVES][CIRCLE ? 1 : 2][TILE_ROWS];
+  __shared__ T s_wc[WAVES][2][TILE_ROWS];
   // fp32 fused log_prob: log C_m(kappa) and kappa of the tile's rows (kappa is read from HBM once per row)
   // (not for the circle: one lane owns a row there, so log p is formed and stored in phase 2 directly)
   constexpr bool LP_SLAB = sizeof(T) == 4 && !CIRCLE;
@@ -250,13 +248,13 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
   const int m = FAST ? 4 * LPR * P : (CIRCLE ? 2 : p.m);
   const bool pre = !FAST && !CIRCLE && p.prop_e != nullptr;
   // Circle (m = 2) with counter noise: a proposal needs two uniforms (the Beta(1/2,1/2) angle and the accept draw)
-  // and the tangent "direction" is one sign, so one Philox call serves two proposals (words x,y then z,w of call
-  // k >> 1) and bit 0 of the first call's word x (below the 23 bits u01 uses) is the sign.  The sign travels to
-  // phase 2 in the sign bit of the parked word (see circle_pack).
+  // and the tangent "direction" is one sign, so one Philox call serves two proposals; the counter layout, and the
+  // arithmetic shared with vmf_circle_fwd_kernel, are described with circle_try in vmf_math.h.  The slabs hold w and
+  // the signed sqrt(1 - w^2).
   // MODE 3 is this case with m a compile-time 2 and 64-bit accesses; MODE 0 takes it when rows are not 8-byte aligned.
   const bool circle = CIRCLE || (LPR == 1 && MODE == 0 && m == 2 && !pre && p.gauss == nullptr);
   T* const somw = s_wc[wave][0];
-  T* const sw = s_wc[wave][CIRCLE ? 0 : 1];  // not used by the circle instantiation
+  T* const sw = s_wc[wave][1];
   float* const slc = s_lc[LP_SLAB ? wave : 0];
   float* const skp = s_kp[LP_SLAB ? wave : 0];
 
@@ -287,7 +285,7 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
           slc[i] = vmf_log_norm_f32v(p.lc_v, p.lc_lg, p.lc_c0, (float)kap);
         }
         // b(kappa) of every row of the tile, coalesced, parked in the slab that later receives 1 - w^2
-        if (!pre) somw[i] = wood_b<T>(kap, m);
+        if (!pre) somw[i] = circle ? circle_b<T>(kap) : wood_b<T>(kap, m);
       }
       wave_lds_sync();
     }
@@ -310,17 +308,27 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
             acc = wood_try<T>(a, b, d, m, p.prop_e[row * p.max_prop + k], p.prop_u[row * p.max_prop + k], &w, &omw);
             c2 = omw * ((T)1 + w);
           } else if (LPR == 1 && circle) {
-            // k is even here: both proposals of call k / 2 are evaluated in this iteration and the first accepted
-            // one wins (the same decision sequence as one proposal per iteration, in half the Philox calls -- lanes
-            // of a wave sit at different k, so skipping the call on odd k would not shorten the wave's iteration)
-            const U4 rc = philox4x32_10(grow0 + (uint64_t)my, (uint32_t)(k >> 1), key);
-            if (k == 0) neg = (rc.x & 1u) != 0u;
-            T pc1, ps1;
-            const bool a0 = wood_try_circle<T>(b, u01<T>(rc.x), u01<T>(rc.y), &pc, &ps);
-            const bool a1 = wood_try_circle<T>(b, u01<T>(rc.z), u01<T>(rc.w), &pc1, &ps1);
-            const bool use0 = a0 || k + 1 >= p.max_prop;
-            acc = use0 || a1;
-            if (!use0) { pc = pc1; ps = ps1; ++k; }
+            const uint64_t grow = grow0 + (uint64_t)my;
+            const T hb = circle_hb<T>(b);
+            if (k == 0) {
+              // the first proposal: half of the call this row shares with its neighbour
+              const U4 rc = philox4x32_10(grow >> 1, 0u, key);
+              const bool odd = (grow & 1u) != 0u;
+              const uint32_t xv = odd ? rc.z : rc.x, xu = odd ? rc.w : rc.y;
+              neg = (xv & 1u) != 0u;
+              acc = circle_try<T>(b, hb, xv, xu, &pc, &ps);
+            } else {
+              // k is odd here: both proposals of the row's own call (k - 1) / 2 are evaluated in this iteration and the
+              // first accepted one wins (the same decision sequence as one proposal per iteration, in half the calls --
+              // lanes of a wave sit at different k, so skipping the call on even k would not shorten the iteration)
+              const U4 rc = philox4x32_10(grow, 1u + (uint32_t)(k >> 1), key);
+              T pc1, ps1;
+              const bool a0 = circle_try<T>(b, hb, rc.x, rc.y, &pc, &ps);
+              const bool a1 = circle_try<T>(b, hb, rc.z, rc.w, &pc1, &ps1);
+              const bool use0 = a0 || k + 1 >= p.max_prop;
+              acc = use0 || a1;
+              if (!use0) { pc = pc1; ps = ps1; ++k; }
+            }
           } else {
             const U4 r = philox4x32_10(grow0 + (uint64_t)my, (uint32_t)k, key);
             acc = wood_try_counter<T>(b, m, u01<T>(r.x), u01<T>(r.y), u01<T>(r.z), &w, &omw, &c2);
@@ -330,12 +338,8 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
             // sqrt((1 - w)(1 + w)) -- 1 + w taken where it is known without cancellation -- is what phase 2 multiplies
             // by: the root is taken here, once per row, instead of by every lane of the row's group at every step
             T parked = F<T>::sqrt(c2 < (T)1e-10 ? (T)1e-10 : c2);
-            if (LPR == 1 && circle) {
-              parked = circle_pack((T)2 * b * pc, (T)2 * ps, neg);
-              T opw;
-              circle_unpack(parked, &w, &omw, &opw);  // w and 1 - w as phase 2 will see them
-            }
-            if (!CIRCLE) sw[my] = w;
+            if (LPR == 1 && circle) circle_finish<T>(b, pc, ps, neg, &w, &omw, &parked);
+            sw[my] = w;
             somw[my] = parked;
             if (p.w_out) p.w_out[tile0 + my] = w;
             if (p.omw_out) p.omw_out[tile0 + my] = omw;
@@ -386,6 +390,41 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
       const bool valid = r < ntile;
       const int rr = valid ? r : 0;
       const T* mrow = mu_t + rr * p.mu_stride;
+      if (LPR == 1 && circle) {
+        // the circle: one lane, one row; w and the signed sqrt(1 - w^2) come from the slabs, the reflection from the
+        // function vmf_circle_fwd_kernel uses
+        T m0, m1;
+        if (CIRCLE) {
+          const Pair<T> v = *reinterpret_cast<const Pair<T>*>(mrow);
+          m0 = v.a; m1 = v.b;
+        } else {
+          m0 = mrow[0]; m1 = mrow[1];
+        }
+        T z0, z1, mz;
+        circle_compose<T>(m0, m1, sw[rr], somw[rr], p.normalize != 0, &z0, &z1, &mz);
+        if (valid) {
+          T* const zrow = z_t + rr * 2;
+          if (CIRCLE) {
+            Pair<T> o;
+            o.a = z0; o.b = z1;
+            *reinterpret_cast<Pair<T>*>(zrow) = o;
+          } else {
+            zrow[0] = z0; zrow[1] = z1;
+          }
+          if (p.logp) {
+            T sig_;
+            const T kap = kappa_of<T>(kap_t[rr * p.kappa_stride], sp, &sig_);
+            if (sizeof(T) == 4) {
+              const float lpv = vfma((float)kap, (float)mz, vmf_log_norm_circle_f32((float)kap));
+              if (LP_SLAB) slc[rr] = lpv;  // (replaces the general-m log C the prologue parked; stored after the loop)
+              else p.logp[tile0 + rr] = (T)lpv;
+            } else {
+              p.logp[tile0 + rr] += kap * mz;  // log C_2(kappa) came from the pre-pass
+            }
+          }
+        }
+        continue;
+      }
       T mu[P][4], g[P][4];
       const bool more = r0 + RPI < ntile;  // wave-uniform
       if (PF) {
@@ -418,18 +457,8 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
           // than a select, which the compiler widens to the whole 4-vector
           if (j == 0) g[0][0] *= gmask0;
         } else {
-          if (CIRCLE) {
-            const Pair<T> v = *reinterpret_cast<const Pair<T>*>(mrow);
-            mu[j][0] = v.a; mu[j][1] = v.b; mu[j][2] = mu[j][3] = (T)0;
-          } else {
-            load4<T, VEC>(mrow, 4 * chunk, m, mu[j]);
-          }
-          if (LPR == 1 && circle) {
-            g[j][0] = g[j][2] = g[j][3] = (T)0;
-            g[j][1] = __builtin_signbit(somw[rr]) ? (T)-1 : (T)1;
-          } else {
-            noise4<T, VEC>(ga_t ? ga_t + (int64_t)rr * m : nullptr, grow0 + (uint64_t)rr, chunk, m, key, g[j]);
-          }
+          load4<T, VEC>(mrow, 4 * chunk, m, mu[j]);
+          noise4<T, VEC>(ga_t ? ga_t + (int64_t)rr * m : nullptr, grow0 + (uint64_t)rr, chunk, m, key, g[j]);
         }
         if (VMF_PK_SUMS && FAST && sizeof(T) == 4) {
           // the three partial sums in packed pairs (v_pk_mul / v_pk_fma: two lanes of arithmetic per instruction)
@@ -464,16 +493,7 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
       const T d0 = (T)1 - mu0;
       const T tail = dd * (inv * inv);  // |mu|^2 without its first element
       dd = d0 * d0 + tail;              // |e1 - mu|^2
-      T w, sc2;  // w, sqrt(1 - w^2)
-      if (LPR == 1 && circle) {
-        T omw, opw;
-        circle_unpack(somw[rr], &w, &omw, &opw);
-        const T c2 = omw * opw;
-        sc2 = F<T>::sqrt(c2 < (T)1e-10 ? (T)1e-10 : c2);
-      } else {
-        sc2 = somw[rr];
-        w = sw[rr];
-      }
+      const T sc2 = somw[rr], w = sw[rr];  // sqrt(1 - w^2), w
       const T f = sc2 * F<T>::rsqrt(gg);
       const T zd = w * d0 - f * gm;
       const T coef = dd > (T)1e-30 ? (T)2 * zd * F<T>::rcp(dd) : (T)0;
@@ -494,11 +514,7 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
             const bool first = (j == 0 && i == 0 && sub == 0);
             out[i] = first ? w - coef * d0 : f * g[j][i] + coef_mu * mu[j][i];
           }
-          if (CIRCLE) {
-            Pair<T> o;
-            o.a = out[0]; o.b = out[1];
-            *reinterpret_cast<Pair<T>*>(zrow) = o;
-          } else if (FAST) {
+          if (FAST) {
             if (sizeof(T) == 4) {
               // z is written once and not read again by this kernel: stream it past the caches
               f32x4 v4 = {(float)out[0], (float)out[1], (float)out[2], (float)out[3]};
@@ -519,11 +535,6 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
           const T mz = w * mu0 + f * gm - coef * (mu0 * d0 - tail);
           if (LP_SLAB) {
             slc[rr] += skp[rr] * (float)mz;  // written out coalesced once the tile is done
-          } else if (sizeof(T) == 4) {       // circle: consecutive lanes hold consecutive rows
-            T sig_;
-            const float kap = (float)kappa_of<T>(kap_t[rr * p.kappa_stride], sp, &sig_);
-            const float lc = CIRCLE ? vmf_log_norm_circle_f32(kap) : vmf_log_norm_f32v(p.lc_v, p.lc_lg, p.lc_c0, kap);
-            p.logp[tile0 + rr] = (T)(lc + kap * (float)mz);
           } else {
             T sig_;
             p.logp[tile0 + rr] += kappa_of<T>(kap_t[rr * p.kappa_stride], sp, &sig_) * mz;  // log C_m(kappa) came from the pre-pass
@@ -763,6 +774,218 @@ static void launch_rowlane(const FwdParams<float>& p, hipStream_t s) {
   }
 }
 
+// ---- the circle (m = 2), dense 16-byte-aligned fp32 rows, counter noise: TWO rows per lane ---------------------------
+// A circle row is 8 bytes of mu in and 8 bytes of z out against a rejection sampler, so the kernel is bound by the
+// instructions it issues, not by HBM, unless they are cut to the bone.  What this kernel does about it:
+//   * a lane owns the rows 2p, 2p+1 of a 128-row step: one 128-bit access moves both rows of mu / z, one 64-bit access
+//     both concentrations, and ONE Philox call gives both rows their first proposal (see circle_try in vmf_math.h);
+//   * a wave issues every load of its tile (CF_TILE rows) before it computes anything: the kappa loads first (needed
+//     first; the memory counter retires in order), then mu, which lands while the rejection phase runs -- phase 2 never
+//     waits on memory;
+//   * phase 1a evaluates the first proposal of every row, parks (w, signed sqrt(1-w^2)) of the accepted rows in a
+//     wave-private LDS slab and compacts the rejected rows (ballot + prefix popcount) into a wave-private queue;
+//   * phase 1b works the queue off one row per lane, two proposals per Philox call, retiring accepted lanes and
+//     refilling them from the queue through a ballot as the general-m kernel does: its trip count follows the mean
+//     number of further proposals of the REJECTED rows only (a fifth of the tile), about one wave-iteration per 100 rows;
+//   * phase 2 reflects both rows (circle_compose) and streams z out with one 128-bit non-temporal store per lane.
+// Same draws, same bits as the one-row-per-lane instantiations of vmf_rsample_fwd_kernel (MODE 3 / MODE 0), which take
+// every other layout: shards that start on an odd global row, views that are not 16-byte aligned, shared parameters.
+#ifndef VMF_CF_TILE
+#define VMF_CF_TILE 512
+#endif
+constexpr int CF_TILE = VMF_CF_TILE;
+constexpr int CF_STEPS = CF_TILE / 128;
+#ifndef VMF_CF_WAVES_PER_SIMD
+#define VMF_CF_WAVES_PER_SIMD 8
+#endif
+#ifndef VMF_CF_XCD
+#define VMF_CF_XCD 1
+#endif
+#ifndef VMF_CF_NT
+#define VMF_CF_NT 1
+#endif
+__device__ __forceinline__ int lanes_below(unsigned long long mask) {  // set bits of `mask` below this lane
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// OPTS: any of softplus / normalize / kappa_out / w_out / omw_out / accept_idx / logp is in use.  FULL: the tile has all
+// its CF_TILE rows (the ragged last tile runs the same code with guarded accesses; a separate instantiation, so that the
+// full tiles' loads and their waits are straight-line code the compiler can count).
+template <bool OPTS, bool FULL>
+__device__ __forceinline__ void circle_tile(const FwdParams<float>& p, const PhiloxKey key, float* const park,
+                                            uint16_t* const queue, const int64_t tile0, const int ntile, const int lane) {
+  constexpr bool full = FULL;
+  const float* const kap_t = p.kappa + tile0;
+  const float* const mu_t = p.mu + 2 * tile0;
+  float* const z_t = p.z + 2 * tile0;
+  const uint64_t grow0 = p.row0 + (uint64_t)tile0;  // even: the launch code sends odd row offsets to the other kernel
+  const bool normalize = OPTS && p.normalize != 0;
+
+  // ---- every load of the tile ----
+  f32x2 kap[CF_STEPS];
+  f32x4 mu[CF_STEPS];
+  if (full) {
+#pragma unroll
+    for (int s = 0; s < CF_STEPS; ++s)
+      kap[s] = VMF_CF_NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(kap_t) + 64 * s + lane)
+                         : reinterpret_cast<const f32x2*>(kap_t)[64 * s + lane];
+#pragma unroll
+    for (int s = 0; s < CF_STEPS; ++s)
+      mu[s] = VMF_CF_NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mu_t) + 64 * s + lane)
+                        : reinterpret_cast<const f32x4*>(mu_t)[64 * s + lane];
+  } else {
+#pragma unroll
+    for (int s = 0; s < CF_STEPS; ++s) {
+      const int rA = 128 * s + 2 * lane;
+      kap[s].x = rA < ntile ? kap_t[rA] : 1.0f;
+      kap[s].y = rA + 1 < ntile ? kap_t[rA + 1] : 1.0f;
+      f32x2 a = {1.0f, 0.0f}, b = {1.0f, 0.0f};
+      if (rA < ntile) a = *reinterpret_cast<const f32x2*>(mu_t + 2 * rA);
+      if (rA + 1 < ntile) b = *reinterpret_cast<const f32x2*>(mu_t + 2 * rA + 2);
+      mu[s] = f32x4{a.x, a.y, b.x, b.y};
+    }
+  }
+
+  // ---- phase 1a: the first proposal of every row ----
+  int qn = 0;  // rows waiting for further proposals (wave-uniform)
+  const bool forced0 = p.max_prop <= 1;  // the last proposal allowed is taken regardless
+#pragma unroll
+  for (int s = 0; s < CF_STEPS; ++s) {
+    const int rA = 128 * s + 2 * lane;
+    float kA = kap[s].x, kB = kap[s].y;
+    if (OPTS) {
+      if (p.softplus) {
+        float sig_;
+        kA = kappa_of<float>(kA, true, &sig_);
+        kB = kappa_of<float>(kB, true, &sig_);
+        kap[s] = f32x2{kA, kB};
+      }
+      if (p.kappa_out) {
+        if (rA < ntile) p.kappa_out[tile0 + rA] = kA;
+        if (rA + 1 < ntile) p.kappa_out[tile0 + rA + 1] = kB;
+      }
+    }
+    const U4 r = philox4x32_10((grow0 >> 1) + (uint64_t)(64 * s + lane), 0u, key);
+    const float bA = circle_b<float>(kA), bB = circle_b<float>(kB);
+    float pcA, psA, pcB, psB;
+    const bool accA = circle_try<float>(bA, circle_hb<float>(bA), r.x, r.y, &pcA, &psA) || forced0;
+    const bool accB = circle_try<float>(bB, circle_hb<float>(bB), r.z, r.w, &pcB, &psB) || forced0;
+    const bool negA = (r.x & 1u) != 0u, negB = (r.z & 1u) != 0u;
+    float wA, omwA, fsA, wB, omwB, fsB;
+    circle_finish<float>(bA, pcA, psA, negA, &wA, &omwA, &fsA);
+    circle_finish<float>(bB, pcB, psB, negB, &wB, &omwB, &fsB);
+    // accepted: (w, signed sqrt(1-w^2)); rejected: (b, the sign) for phase 1b
+    const f32x4 pk = {accA ? wA : bA, accA ? fsA : (negA ? -1.0f : 1.0f), accB ? wB : bB,
+                      accB ? fsB : (negB ? -1.0f : 1.0f)};
+    *reinterpret_cast<f32x4*>(park + 2 * rA) = pk;
+    const bool rejA = !accA && rA < ntile, rejB = !accB && rA + 1 < ntile;
+    const unsigned long long mA = __ballot(rejA), mB = __ballot(rejB);
+    if (rejA) queue[qn + lanes_below(mA)] = (uint16_t)rA;
+    qn += __popcll(mA);
+    if (rejB) queue[qn + lanes_below(mB)] = (uint16_t)(rA + 1);
+    qn += __popcll(mB);
+    if (OPTS) {
+      if (accA && rA < ntile) {
+        if (p.w_out) p.w_out[tile0 + rA] = wA;
+        if (p.omw_out) p.omw_out[tile0 + rA] = omwA;
+        if (p.accept_idx) p.accept_idx[tile0 + rA] = 0;
+      }
+      if (accB && rA + 1 < ntile) {
+        if (p.w_out) p.w_out[tile0 + rA + 1] = wB;
+        if (p.omw_out) p.omw_out[tile0 + rA + 1] = omwB;
+        if (p.accept_idx) p.accept_idx[tile0 + rA + 1] = 0;
+      }
+    }
+  }
+  wave_lds_sync();
+
+  // ---- phase 1b: further proposals of the rejected rows, one row per lane, ballot refill from the queue ----
+  {
+    int my = lane, next = 64, t = 0, row = 0;
+    bool active = my < qn;
+    float b = 0.0f, hb = 0.0f, sg = 1.0f;
+    if (active) {
+      row = queue[my];
+      const f32x2 e = *reinterpret_cast<const f32x2*>(park + 2 * row);
+      b = e.x; sg = e.y; hb = circle_hb<float>(b);
+    }
+    while (__ballot(active) != 0ull) {
+      bool acc = false;
+      if (active) {
+        const U4 rc = philox4x32_10(grow0 + (uint64_t)row, 1u + (uint32_t)t, key);
+        int k = 1 + 2 * t;
+        float pc, ps, pc1, ps1;
+        const bool a0 = circle_try<float>(b, hb, rc.x, rc.y, &pc, &ps);
+        const bool a1 = circle_try<float>(b, hb, rc.z, rc.w, &pc1, &ps1);
+        const bool use0 = a0 || k + 1 >= p.max_prop;
+        acc = use0 || a1 || k + 2 >= p.max_prop;
+        if (!use0) { pc = pc1; ps = ps1; ++k; }
+        if (acc) {
+          float w, omw, fs;
+          circle_finish<float>(b, pc, ps, sg < 0.0f, &w, &omw, &fs);
+          *reinterpret_cast<f32x2*>(park + 2 * row) = f32x2{w, fs};
+          if (OPTS) {
+            if (p.w_out) p.w_out[tile0 + row] = w;
+            if (p.omw_out) p.omw_out[tile0 + row] = omw;
+            if (p.accept_idx) p.accept_idx[tile0 + row] = k;
+          }
+        }
+        ++t;
+      }
+      const unsigned long long accm = __ballot(acc);
+      if (acc) {
+        my = next + lanes_below(accm);
+        t = 0;
+        active = my < qn;
+        if (active) {
+          row = queue[my];
+          const f32x2 e = *reinterpret_cast<const f32x2*>(park + 2 * row);
+          b = e.x; sg = e.y; hb = circle_hb<float>(b);
+        }
+      }
+      next += __popcll(accm);
+    }
+  }
+  wave_lds_sync();
+
+  // ---- phase 2: reflect and store ----
+#pragma unroll
+  for (int s = 0; s < CF_STEPS; ++s) {
+    const int rA = 128 * s + 2 * lane;
+    const f32x4 pk = *reinterpret_cast<const f32x4*>(park + 2 * rA);
+    float zA0, zA1, mzA, zB0, zB1, mzB;
+    circle_compose<float>(mu[s].x, mu[s].y, pk.x, pk.y, normalize, &zA0, &zA1, &mzA);
+    circle_compose<float>(mu[s].z, mu[s].w, pk.z, pk.w, normalize, &zB0, &zB1, &mzB);
+    if (full) {
+      store_nt(f32x4{zA0, zA1, zB0, zB1}, z_t + 4 * (64 * s + lane));
+    } else {
+      if (rA < ntile) *reinterpret_cast<f32x2*>(z_t + 2 * rA) = f32x2{zA0, zA1};
+      if (rA + 1 < ntile) *reinterpret_cast<f32x2*>(z_t + 2 * rA + 2) = f32x2{zB0, zB1};
+    }
+    if (OPTS && p.logp) {
+      const float kA = kap[s].x, kB = kap[s].y;
+      if (rA < ntile) p.logp[tile0 + rA] = vfma(kA, mzA, vmf_log_norm_circle_f32(kA));
+      if (rA + 1 < ntile) p.logp[tile0 + rA + 1] = vfma(kB, mzB, vmf_log_norm_circle_f32(kB));
+    }
+  }
+}
+template <bool OPTS>
+__global__ __launch_bounds__(WAVES * 64, VMF_CF_WAVES_PER_SIMD) void vmf_circle_fwd_kernel(FwdParams<float> p) {
+  __shared__ __align__(16) float s_park[WAVES][2 * CF_TILE];
+  __shared__ uint16_t s_queue[WAVES][CF_TILE];
+  const PhiloxKey key = philox_resolve(p.ka);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#if VMF_CF_XCD
+  const uint32_t bid = xcd_block(blockIdx.x, gridDim.x);
+#else
+  const uint32_t bid = blockIdx.x;
+#endif
+  const int64_t tile0 = ((int64_t)bid * WAVES + wave) * CF_TILE;  // wave-uniform
+  const int64_t left = p.n - tile0;
+  if (left <= 0) return;  // the kernel has no workgroup barrier
+  if (left >= CF_TILE) circle_tile<OPTS, true>(p, key, s_park[wave], s_queue[wave], tile0, CF_TILE, lane);
+  else circle_tile<OPTS, false>(p, key, s_park[wave], s_queue[wave], tile0, (int)left, lane);
+}
+
 // Backward: one pass over (grad_z, mu) rows; normals regenerated from the counters unless given.
 template <typename T, int LPR, int P, bool VEC>
 __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T> p) {
@@ -790,9 +1013,10 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
       load4<T, VEC, VMF_BWD_STREAM>(mrow, 4 * chunk, m, mu[j]);
       load4<T, VEC, VMF_BWD_STREAM>(grow_, 4 * chunk, m, G[j]);
       if (LPR == 1 && m == 2 && p.gauss == nullptr) {  // circle: the tangent is the sign bit of the row's first call
-        const U4 r0 = philox4x32_10(p.row0 + (uint64_t)row, 0u, key);
+        const uint64_t grow = p.row0 + (uint64_t)row;
+        const U4 r0 = philox4x32_10(grow >> 1, 0u, key);
         g[j][0] = g[j][2] = g[j][3] = (T)0;
-        g[j][1] = (r0.x & 1u) ? (T)-1 : (T)1;
+        g[j][1] = (((grow & 1u) ? r0.z : r0.x) & 1u) ? (T)-1 : (T)1;
       } else {
         noise4<T, VEC>(p.gauss ? p.gauss + row * (int64_t)m : nullptr, p.row0 + (uint64_t)row, chunk, m, key, g[j]);
       }
@@ -1198,6 +1422,19 @@ static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
     if (rowlane_ok(m) && !prop_e) {
       p.dense16 = mu_stride == m && aligned16(mu) && aligned16(z);
       launch_rowlane(p, s);
+      return VMF_OK;
+    }
+  }
+  if constexpr (sizeof(T) == 4) {
+    // dense aligned circles whose pairs of rows (2p, 2p+1) in the GLOBAL numbering are 16-byte units: two rows per lane
+    if (pair_ok && mu_stride == 2 && kappa_stride == 1 && (row0 & 1u) == 0 && aligned16(mu) && aligned16(z) &&
+        ((uintptr_t)kappa & 7u) == 0) {
+      const int64_t nt = (n + CF_TILE - 1) / CF_TILE;
+      const int64_t nb = (nt + WAVES - 1) / WAVES;
+      VMF_REQUIRE(nb <= 0x7fffffff, VMF_ERR_UNSUPPORTED, "n=%lld rows need more than 2^31 workgroups", (long long)n);
+      const bool opts = p.softplus || p.normalize || kappa_out || w_out || omw_out || accept_idx || logp_out;
+      if (opts) hipLaunchKernelGGL((vmf_circle_fwd_kernel<true>), dim3((unsigned)nb), dim3(WAVES * 64), 0, s, p);
+      else hipLaunchKernelGGL((vmf_circle_fwd_kernel<false>), dim3((unsigned)nb), dim3(WAVES * 64), 0, s, p);
       return VMF_OK;
     }
   }

@@ -596,54 +596,96 @@ __device__ __forceinline__ bool wood_try_counter(T b, int m, T U, T V, T uacc, T
   return (T)(m - 1) * F<T>::log1p_minus_over_ln2(s) >= F<T>::log2(uacc);  // both sides divided by ln 2
 }
 
-// Circle (m = 2): the proposal cosine c = cos 2 pi V follows the arcsine law, half its mass near -1 and +1, where
-// 1 + c, 1 - c and the denominator cancel in turn.  The half angle gives every factor without cancellation:
+// ---- circle (m = 2), counter noise ------------------------------------------------------------------------------
+// Noise layout (shared with the CPU checker): the FIRST proposal of rows 2p and 2p+1 comes from ONE Philox call
+//   Philox(index = p = row >> 1, slot 0): words (x, y) serve the even row, (z, w) the odd one -- the first word gives
+//   the proposal's angle V = u01(word) and, in its bit 0 (below the 23 bits u01 uses), the sign of the tangent; the
+//   second word is the accept draw.
+// A row whose first proposal is rejected (about a fifth of them for kappa >= 10) continues on calls of its own:
+//   Philox(index = row, slot 1 + t), t = 0, 1, ...: proposals 1 + 2t from (x, y) and 2 + 2t from (z, w).
+// So a pair of rows costs one call, plus one per further two proposals of a rejected row.
+//
+// The proposal cosine c = cos 2 pi V follows the arcsine law, half its mass near -1 and +1, where 1 + c, 1 - c and
+// the denominator cancel in turn.  The half angle gives every factor without cancellation:
 //   1 + c = 2 cos^2(pi V),  1 - c = 2 sin^2(pi V),  den = 1 - (1-b)(1+c)/2 = b cos^2 + sin^2,
 //   1 - w = 2 b cos^2 / den,  1 + w = 2 sin^2 / den
-// and both 1 - w and 1 + w are carried to the composition (an accepted w within 1e-6 of -1 is rare but happens at kappa ~ 1, and
-// 1 + w formed from the rounded w loses its digits there: 1e-4 in z).
+// and sqrt(1 - w^2) is taken from the product of the two (an accepted w within 1e-6 of -1 is rare but happens at
+// kappa ~ 1, and 1 + w formed from the rounded w loses its digits there: 1e-4 in z).
+//
+// Two kernels draw circle rows (two rows per lane for dense aligned tensors, one row per lane for every other layout)
+// and a shard must reproduce the unsharded rows bit for bit whichever of them it lands in: the functions below fix
+// every rounding (no contraction left to the compiler) and both kernels call them.
+__device__ __forceinline__ float vfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double vfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// u01(x) / 2, exact: the angle pi V as the argument, in revolutions, of the hardware sine / cosine
 template <typename T>
-__device__ __forceinline__ bool wood_try_circle(T b, T V, T uacc, T* pc, T* ps) {
-  // returns cos^2 / den and sin^2 / den; the caller forms 1 - w = 2 b pc and 1 + w = 2 ps for the proposal it keeps
+__device__ __forceinline__ T u01_half(uint32_t x) { return (T)0.5 * u01<T>(x); }
+template <>
+__device__ __forceinline__ float u01_half<float>(uint32_t x) {
+  // the 23 bits under the exponent of 1/2 give 1/2 + (x >> 9) 2^-24 in [1/2, 1); subtracting 1/2 - 2^-25 is exact
+  return __uint_as_float(__builtin_amdgcn_alignbit(0x7Eu, x, 9u)) - 0.49999997f;
+}
+
+// b(kappa) = 1 / (2 kappa + sqrt(4 kappa^2 + 1))
+template <typename T>
+__device__ __forceinline__ T circle_b(T kappa) {
+  return F<T>::rcp(vfma((T)2, kappa, F<T>::sqrt(vfma((T)4 * kappa, kappa, (T)1))));
+}
+
+// One proposal from the words (xv, xu); hb = (1 - b) / 2.  Returns cos^2 / den and sin^2 / den; the caller forms
+// 1 - w = 2 b pc and 1 + w = 2 ps for the proposal it keeps.
+template <typename T>
+__device__ __forceinline__ bool circle_try(T b, T hb, uint32_t xv, uint32_t xu, T* pc, T* ps) {
+#pragma clang fp contract(off)
   T sh, ch;
-  F<T>::sincos2pi((T)0.5 * V, &sh, &ch);
+  F<T>::sincos2pi(u01_half<T>(xv), &sh, &ch);
   const T ch2 = ch * ch, sh2 = sh * sh;
-  const T rden = F<T>::rcp(b * ch2 + sh2);
+  const T rden = F<T>::rcp(vfma(b, ch2, sh2));
   *pc = ch2 * rden;
   *ps = sh2 * rden;
-  const T s = ((T)0.5 - (T)0.5 * b) * (*pc - *ps);  // (1-b) c / (2 den)
+  const T s = hb * (*pc - *ps);  // (1-b) c / (2 den)
   // m - 1 = 1, so log(1+s) - s >= ln u can be tested as 1 + s >= u e^s: one exponential instead of two logarithms
-  return (T)1 + s >= uacc * F<T>::exp2((T)1.44269504088896340736 * s);
+  return (T)1 + s >= u01<T>(xu) * F<T>::exp2((T)1.44269504088896340736 * s);
 }
-// One LDS word per accepted circle row: the smaller of 1 - w and 1 + w (so that the other one, 2 minus it, is exact to
-// an ulp of 2 and w = +-(1 - it) keeps its digits at both ends), which of the two in the mantissa's last bit, and the
-// tangent's sign in the sign bit.
-__device__ __forceinline__ float circle_pack(float omw, float opw, bool neg) {
-  const bool hi = omw > 1.0f;
-  const uint32_t bits = (__float_as_uint(hi ? opw : omw) & 0x7ffffffeu) | (hi ? 1u : 0u) | (neg ? 0x80000000u : 0u);
-  return __uint_as_float(bits);
+template <typename T>
+__device__ __forceinline__ T circle_hb(T b) { return vfma((T)-0.5, b, (T)0.5); }
+
+// The accepted proposal as the composition needs it: w, 1 - w (exact where w is close to 1) and the signed
+// sqrt(1 - w^2) = the tangent component of z' (the tangent "direction" on a circle is one sign).
+template <typename T>
+__device__ __forceinline__ void circle_finish(T b, T pc, T ps, bool neg, T* w, T* omw, T* fs) {
+#pragma clang fp contract(off)
+  const T om = ((T)2 * b) * pc, op = (T)2 * ps;
+  T c2 = om * op;
+  c2 = c2 < (T)1e-10 ? (T)1e-10 : c2;
+  const T sc = F<T>::sqrt(c2);
+  const bool hi = om > (T)1;  // w < 0: 1 + w is the small, exactly known one
+  *w = hi ? op - (T)1 : (T)1 - om;
+  *omw = hi ? (T)2 - op : om;
+  *fs = neg ? -sc : sc;
 }
-__device__ __forceinline__ double circle_pack(double omw, double opw, bool neg) {
-  const bool hi = omw > 1.0;
-  const unsigned long long bits = ((unsigned long long)__double_as_longlong(hi ? opw : omw) & 0x7ffffffffffffffeull) |
-                                  (hi ? 1ull : 0ull) | (neg ? 0x8000000000000000ull : 0ull);
-  return __longlong_as_double((long long)bits);
-}
-__device__ __forceinline__ void circle_unpack(float x, float* w, float* omw, float* opw) {
-  const uint32_t bits = __float_as_uint(x);
-  const float v = __uint_as_float(bits & 0x7ffffffeu);
-  const bool hi = (bits & 1u) != 0u;
-  *omw = hi ? 2.0f - v : v;
-  *opw = hi ? v : 2.0f - v;
-  *w = hi ? v - 1.0f : 1.0f - v;
-}
-__device__ __forceinline__ void circle_unpack(double x, double* w, double* omw, double* opw) {
-  const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
-  const double v = __longlong_as_double((long long)(bits & 0x7ffffffffffffffeull));
-  const bool hi = (bits & 1ull) != 0ull;
-  *omw = hi ? 2.0 - v : v;
-  *opw = hi ? v : 2.0 - v;
-  *w = hi ? v - 1.0 : 1.0 - v;
+
+// z = H (w, fs) with H the Householder reflection e1 -> mu (mu / ||mu|| when `normalize`), and <mu, z> for log p:
+//   z = z' - 2 <z', d> d / <d, d>,  d = e1 - mu
+// <mu, z> = <mu, z'> - coef <mu, d> with <mu, d> = mu0 (1 - mu0) - mu1^2: written through the two small quantities,
+// because coef ~ 1 / |d|^2 multiplies it and mu0 - |mu|^2 formed from rounded values near 1 loses everything when mu is
+// close to the pole (for one row in a few hundred it is).
+template <typename T>
+__device__ __forceinline__ void circle_compose(T mu0, T mu1, T w, T fs, bool normalize, T* z0, T* z1, T* mz) {
+#pragma clang fp contract(off)
+  T inv = (T)1;
+  if (normalize) inv = F<T>::rsqrt(vfma(mu1, mu1, mu0 * mu0));
+  const T m0 = mu0 * inv, m1 = mu1 * inv;
+  const T d0 = (T)1 - m0;
+  const T tail = m1 * m1;
+  const T dd = vfma(d0, d0, tail);  // |e1 - mu|^2
+  const T fm = fs * m1;
+  const T zd = vfma(w, d0, -fm);    // <z', d>
+  const T coef = dd > (T)1e-30 ? ((T)2 * zd) * F<T>::rcp(dd) : (T)0;
+  *z0 = vfma(-coef, d0, w);
+  *z1 = vfma(coef, m1, fs);
+  *mz = vfma(w, m0, fm) - coef * vfma(m0, d0, -tail);
 }
 
 // b(kappa) alone (what the counter-based path needs)
