@@ -84,6 +84,11 @@ def launch_ranks(a):
         port = s.getsockname()[1]
     procs = []
     for r in range(a.gpus):
+        # HSA_ENABLE_IPC_MODE_LEGACY: RCCL's intra-node transport shares device buffers between the rank processes
+        # through IPC handles.  The hosts this runs on support only the dmabuf flavour of that; with the runtime's legacy
+        # mode (its default when the variable is unset) hipIpcGetMemHandle fails with "invalid argument" and the
+        # communicator never comes up.  The launching environment normally exports 0 already: an existing value is kept,
+        # and only an unset variable is filled in for the ranks started here.
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
@@ -236,21 +241,21 @@ class Reference3D:
         self.nd = len(plan["odims"])
         self.pa = [_lib.i64_array(plan[k]) for k in ("odims", "w_str", "k_str", "l_str", "e_str")]
         self.sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        self.seed = 0x5EED + rank
+        self.seed, self.row0 = 0x5EED, rank * n  # one batch sharded by rows: the in-kernel noise is keyed by the global row
         self.units, self.dtype, self.unit = n, "f32", "samples/s"
         self.bytes_per_unit = 28
         self.kernel = "vmf3_rows_kernel"
         self.metric = f"VonMisesFisher3D rsample + KL samples/sec (m=3, batch {n})"
         self.workload = (f"VonMisesFisher3D(loc, kappa in [1,100]).rsample() of {n} rows per GPU (in-kernel Philox) + mean "
                          f"KL against the uniform prior (spherical_vae's piecewise form), two launches per step")
-        self.config = {"rows_per_gpu": n, "m": 3, "sharding": "replicas"}
+        self.config = {"rows_per_gpu": n, "m": 3, "sharding": "rows, no data-path collective"}
 
     def step(self, i, ev):
         _lib = self._lib
         if ev:
             ev[0].record()
         rc = self.lib.vmf3_rsample_fwd(_lib.ptr(self.loc), _lib.ptr(self.kappa), None, None, _lib.ptr(self.z), None, None,
-                                       self.nd, *self.pa, 0, _lib.VMF_F32, self.seed, i, None, self.sp)
+                                       self.nd, *self.pa, 0, _lib.VMF_F32, self.row0, self.seed, i, None, self.sp)
         if ev:
             ev[1].record()
         rc = rc or self.lib.vmf_kl_fwd(_lib.ptr(self.kappa), None, _lib.ptr(self.kl), _lib.ptr(self.ws), 1.0 / self.n, self.n,
@@ -524,6 +529,17 @@ def run_rank(a):
             os.dup2(keep, 1)
             os.close(keep)
     ranks_seen = dist.get_world_size() if use_dist else 1
+    # which GPU this rank really runs on (ordinal + PCI address + uuid): an N-rank line must show N distinct devices
+    if gpu:
+        pr = torch.cuda.get_device_properties(dev)
+        pci = "{:04x}:{:02x}:{:02x}".format(*(int(getattr(pr, k, -1)) & 0xffff for k in
+                                             ("pci_domain_id", "pci_bus_id", "pci_device_id")))
+        my_dev = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "ordinal": local, "pci": pci,
+                  "uuid": str(getattr(pr, "uuid", "")), "name": pr.name,
+                  "visible": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))}
+    else:
+        my_dev = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "ordinal": None, "pci": None,
+                  "pid": os.getpid()}
     if a.gpus != world and rank == 0:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     cdev = dev if backend == "nccl" else torch.device("cpu")  # where collectives on scalars live
@@ -585,6 +601,10 @@ def run_rank(a):
         every = [torch.zeros_like(mine) for _ in range(ranks_seen)]
         dist.all_gather(every, mine)
         per_rank_kernel_ms = [float(x.item()) if float(x.item()) >= 0 else None for x in every]
+        devices = [None] * ranks_seen
+        dist.all_gather_object(devices, my_dev)
+    else:
+        devices = [my_dev]
     wl.check()
 
     if rank == 0:
@@ -604,6 +624,8 @@ def run_rank(a):
             "config": dict({"workload": wl.workload, "bench_config": a.config}, **wl.config),
             "ranks_seen": ranks_seen,
             "kernel_ms_per_rank": per_rank_kernel_ms,
+            "devices": devices,
+            "distinct_devices": len({(d.get("pci"), d.get("uuid")) for d in devices}) if gpu else None,
         }
         if a.rehearse:
             out["rehearsal"] = True

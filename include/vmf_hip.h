@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VMF_HIP_VERSION 131
+#define VMF_HIP_VERSION 140
 
 typedef void* vmf_stream_t; /* hipStream_t */
 
@@ -79,8 +79,11 @@ const char* vmf_last_error_string(void);
  *   l = loc/(||loc||+1e-5);  w = 1 + logsumexp(log u, log(1-u) - 2k)/k;  v = normalise(eps - <eps,l> l);
  *   z = w l + sqrt(clamp(1-w^2, 1e-10, 1)) v.
  * u / eps may be null: then both come from Philox(index, slot 0) = (x, y, z, w), 23 bits per uniform: u[i] from the
- * upper bits of x of index i; eps row j = Box-Muller(y, z) -> eps0, eps1 and Box-Muller(w, t) -> eps2 (cosine branch)
- * of index j, t being the lower 9 bits of x, y, z side by side.  w_out (nullable) receives w, indexed like u; kappa_out (nullable) receives the kappa the
+ * upper bits of x of index row0 + i; eps row j = Box-Muller(y, z) -> eps0, eps1 and Box-Muller(w, t) -> eps2 (cosine
+ * branch) of index row0 + j, t being the lower 9 bits of x, y, z side by side.  row0 is the GLOBAL index of the call's
+ * first u element / eps row: a rank that holds rows [a, b) of a batch passes row0 = a and draws exactly the rows the
+ * unsharded call draws (both broadcast shapes with kernels of their own: (B,) and (B, 1) scale; with sample dimensions
+ * in front it is a plain offset into the flattened u / eps tensors).  The backward entry points take the same row0.  w_out (nullable) receives w, indexed like u; kappa_out (nullable) receives the kappa the
  * kernel used, indexed like scale (of interest with VMF_FLAG_SOFTPLUS_KAPPA: the KL term needs it).
  * fp32 calls evaluate log / exp / sqrt / 1/x with the 1-ulp hardware instructions, fp64 calls with the accurate
  * library.  Two broadcast shapes have kernels of their own (vmf3_broadcast_kind tells which a call is): every operand
@@ -88,7 +91,7 @@ const char* vmf_last_error_string(void);
  * scale produces ((B, B, 3), model/spherical_vae.py:81-83). */
 int vmf3_rsample_fwd(const void* loc, const void* scale, const void* u, const void* eps, void* z, void* w_out,
                      void* kappa_out, int ndim, const int64_t* odims, const int64_t* w_str, const int64_t* k_str,
-                     const int64_t* l_str, const int64_t* e_str, int flags, int dtype, uint64_t seed, uint64_t offset,
+                     const int64_t* l_str, const int64_t* e_str, int flags, int dtype, uint64_t row0, uint64_t seed, uint64_t offset,
                      const uint64_t* offset_dev, vmf_stream_t stream);
 
 /* 1: every operand is indexed by the output row; 2: outer product (*n_i = elements of u / scale, *n_j = rows of
@@ -107,7 +110,7 @@ int vmf3_broadcast_kind(int ndim, const int64_t* odims, const int64_t* w_str, co
 int vmf3_rsample_bwd(const void* loc, const void* scale, const void* u, const void* eps, const void* grad_z,
                      const void* grad_kappa, void* dloc, void* dscale, int64_t n_loc, int64_t n_scale, int ndim,
                      const int64_t* odims, const int64_t* w_str, const int64_t* k_str, const int64_t* l_str,
-                     const int64_t* e_str, int flags, int dtype, uint64_t seed, uint64_t offset,
+                     const int64_t* e_str, int flags, int dtype, uint64_t row0, uint64_t seed, uint64_t offset,
                      const uint64_t* offset_dev, vmf_stream_t stream);
 
 /* Backward of the outer-product shape (broadcast kind 2: grad_z is (n_i, n_j, 3), u / scale have n_i elements,
@@ -118,17 +121,17 @@ int vmf3_rsample_bwd(const void* loc, const void* scale, const void* u, const vo
 int vmf3_rsample_bwd_outer_workspace(int64_t n_i, int64_t n_j, int dtype, int64_t* bytes_out);
 int vmf3_rsample_bwd_outer(const void* loc, const void* scale, const void* u, const void* eps, const void* grad_z,
                            const void* grad_kappa, void* dloc, void* dscale, int64_t n_i, int64_t n_j, void* workspace,
-                           int64_t workspace_bytes, int flags, int dtype, uint64_t seed, uint64_t offset,
+                           int64_t workspace_bytes, int flags, int dtype, uint64_t row0, uint64_t seed, uint64_t offset,
                            const uint64_t* offset_dev, vmf_stream_t stream);
 
 /* _sample_w3 alone  sampler/von_mises_fisher.py:50-64: w[i] = 1 + logsumexp([log u_i, log(1-u_i) - 2k]) / k with
  * k = scale[i mod n_scale] (u, w have shape sample_shape + scale.shape, n elements); u null: Philox(index i, slot 0),
  * the same stream vmf3_rsample_fwd uses for its u.  bwd writes grad_w[i] * dw/dk per ELEMENT (n values); the caller
  * sums over the sample dimensions. */
-int vmf3_sample_w_fwd(const void* scale, const void* u, void* w, int64_t n, int64_t n_scale, int dtype, uint64_t seed,
+int vmf3_sample_w_fwd(const void* scale, const void* u, void* w, int64_t n, int64_t n_scale, int dtype, uint64_t row0, uint64_t seed,
                       uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream);
 int vmf3_sample_w_bwd(const void* scale, const void* u, const void* grad_w, void* dscale_rows, int64_t n,
-                      int64_t n_scale, int dtype, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                      int64_t n_scale, int dtype, uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                       vmf_stream_t stream);
 
 /* CNN_experiment/von_mises_fisher.py:88-108 with the reference's sign: logp = k<l,x> - lognorm,

@@ -28,15 +28,15 @@ _I64P = C.POINTER(C.c_int64)
 
 # name -> argtypes; every function returns int except the two noted below
 _PROTOS = {
-    "vmf3_rsample_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I64P, _I64P, _I64P, _I64P, _I64P, _I, _I, _U64, _U64, _P,
-                         _P],
+    "vmf3_rsample_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I64P, _I64P, _I64P, _I64P, _I64P, _I, _I, _U64, _U64, _U64,
+                         _P, _P],
     "vmf3_broadcast_kind": [_I, _I64P, _I64P, _I64P, _I64P, _I64P, _I64P, _I64P],
     "vmf3_rsample_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I64P, _I64P, _I64P, _I64P, _I64P, _I, _I,
-                         _U64, _U64, _P, _P],
+                         _U64, _U64, _U64, _P, _P],
     "vmf3_rsample_bwd_outer_workspace": [_I64, _I64, _I, _I64P],
-    "vmf3_rsample_bwd_outer": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _I64, _I, _I, _U64, _U64, _P, _P],
-    "vmf3_sample_w_fwd": [_P, _P, _P, _I64, _I64, _I, _U64, _U64, _P, _P],
-    "vmf3_sample_w_bwd": [_P, _P, _P, _P, _I64, _I64, _I, _U64, _U64, _P, _P],
+    "vmf3_rsample_bwd_outer": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _I64, _I, _I, _U64, _U64, _U64, _P, _P],
+    "vmf3_sample_w_fwd": [_P, _P, _P, _I64, _I64, _I, _U64, _U64, _U64, _P, _P],
+    "vmf3_sample_w_bwd": [_P, _P, _P, _P, _I64, _I64, _I, _U64, _U64, _U64, _P, _P],
     "vmf3_log_prob_ref": [_P, _P, _P, _P, _P, _I64, _I, _P],
     "vmf3_log_prob_ref_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _P],
     "vmf3_mean": [_P, _P, _P, _I64, _I, _P],

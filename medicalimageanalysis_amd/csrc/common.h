@@ -83,6 +83,7 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
 // ---- Philox4x32-10 --------------------------------------------------------------------------
 struct PhiloxKey {
   uint32_t k0, k1, c3;  // key words and the 4th counter word (offset_lo)
+  uint64_t i0;          // m = 3 entry points: global index of the call's first u element / eps row (added by the kernels)
 };
 // What a launch carries: seed, host offset and an optional DEVICE-resident 64-bit offset that is added to the host
 // one when the kernel starts.  With the counter in device memory a captured HIP graph draws fresh noise on every
@@ -90,12 +91,14 @@ struct PhiloxKey {
 struct PhiloxArg {
   uint32_t seed_lo, seed_hi, off_lo, off_hi;
   const uint64_t* dev_offset;
+  uint64_t row0;
 };
-static inline PhiloxArg make_philox_arg(uint64_t seed, uint64_t offset, const uint64_t* dev_offset) {
+static inline PhiloxArg make_philox_arg(uint64_t seed, uint64_t offset, const uint64_t* dev_offset, uint64_t row0 = 0) {
   PhiloxArg a;
   a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
   a.off_lo = (uint32_t)offset; a.off_hi = (uint32_t)(offset >> 32);
   a.dev_offset = dev_offset;
+  a.row0 = row0;
   return a;
 }
 VMF_HD PhiloxKey philox_key_from(uint64_t seed, uint64_t offset) {
@@ -103,13 +106,16 @@ VMF_HD PhiloxKey philox_key_from(uint64_t seed, uint64_t offset) {
   k.k0 = (uint32_t)seed;
   k.k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32);
   k.c3 = (uint32_t)offset;
+  k.i0 = 0;
   return k;
 }
 // uniform across the grid: one scalar load
 __device__ __forceinline__ PhiloxKey philox_resolve(const PhiloxArg& a) {
   uint64_t off = ((uint64_t)a.off_hi << 32) | a.off_lo;
   if (a.dev_offset) off += *a.dev_offset;
-  return philox_key_from(((uint64_t)a.seed_hi << 32) | a.seed_lo, off);
+  PhiloxKey k = philox_key_from(((uint64_t)a.seed_hi << 32) | a.seed_lo, off);
+  k.i0 = a.row0;
+  return k;
 }
 
 struct U4 {

@@ -278,12 +278,12 @@ __global__ __launch_bounds__(256) void vmf3_bwd_kernel(const T* __restrict__ loc
 }
 
 static V3Call make_call(const void* loc, const void* scale, const void* u, const void* eps, int flags, int dtype,
-                        uint64_t seed, uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream) {
+                        uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream) {
   V3Call c = {};
   c.loc = loc; c.scale = scale; c.u = u; c.eps = eps;
   c.softplus = (flags & VMF_FLAG_SOFTPLUS_KAPPA) ? 1 : 0;
   c.dtype = dtype;
-  c.ka = make_philox_arg(seed, offset, offset_dev);
+  c.ka = make_philox_arg(seed, offset, offset_dev, row0);
   c.stream = (hipStream_t)stream;
   return c;
 }
@@ -291,7 +291,7 @@ static V3Call make_call(const void* loc, const void* scale, const void* u, const
 extern "C" int vmf3_rsample_fwd(const void* loc, const void* scale, const void* u, const void* eps, void* z,
                                 void* w_out, void* kappa_out, int ndim, const int64_t* odims, const int64_t* w_str,
                                 const int64_t* k_str, const int64_t* l_str, const int64_t* e_str, int flags, int dtype,
-                                uint64_t seed, uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream) {
+                                uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream) {
   VMF_RANGE("vmf3_rsample_fwd");
   Bcast bc;
   int64_t n_out = 0;
@@ -301,7 +301,7 @@ extern "C" int vmf3_rsample_fwd(const void* loc, const void* scale, const void* 
   VMF_REQUIRE((flags & ~VMF_FLAG_SOFTPLUS_KAPPA) == 0, VMF_ERR_BAD_ARG, "vmf3_rsample_fwd: unknown flags %d", flags);
   if (n_out == 0) return VMF_OK;
   VMF_REQUIRE(loc && scale && z, VMF_ERR_BAD_ARG, "vmf3_rsample_fwd: null loc/scale/z");
-  V3Call c = make_call(loc, scale, u, eps, flags, dtype, seed, offset, offset_dev, stream);
+  V3Call c = make_call(loc, scale, u, eps, flags, dtype, row0, seed, offset, offset_dev, stream);
   c.z = z; c.w_out = w_out; c.kappa_out = kappa_out;
   int64_t n_i = 0, n_j = 0;
   const int kind = bcast_kind(bc, &n_i, &n_j);
@@ -328,7 +328,7 @@ extern "C" int vmf3_rsample_bwd(const void* loc, const void* scale, const void* 
                                 const void* grad_z, const void* grad_kappa, void* dloc, void* dscale, int64_t n_loc,
                                 int64_t n_scale, int ndim, const int64_t* odims, const int64_t* w_str,
                                 const int64_t* k_str, const int64_t* l_str, const int64_t* e_str, int flags, int dtype,
-                                uint64_t seed, uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream) {
+                                uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream) {
   VMF_RANGE("vmf3_rsample_bwd");
   Bcast bc;
   int64_t n_out = 0;
@@ -339,7 +339,7 @@ extern "C" int vmf3_rsample_bwd(const void* loc, const void* scale, const void* 
   VMF_REQUIRE(n_loc >= 0 && n_scale >= 0, VMF_ERR_BAD_ARG, "negative sizes");
   if (n_loc == 0 && n_scale == 0) return VMF_OK;
   VMF_REQUIRE(loc && scale && grad_z && dloc && dscale, VMF_ERR_BAD_ARG, "vmf3_rsample_bwd: null pointer");
-  V3Call c = make_call(loc, scale, u, eps, flags, dtype, seed, offset, offset_dev, stream);
+  V3Call c = make_call(loc, scale, u, eps, flags, dtype, row0, seed, offset, offset_dev, stream);
   c.gz = grad_z; c.gkappa = grad_kappa; c.dloc = dloc; c.dscale = dscale;
   int64_t n_i = 0, n_j = 0;
   const int kind = n_out ? bcast_kind(bc, &n_i, &n_j) : V3_KIND_GENERAL;
@@ -383,7 +383,7 @@ extern "C" int vmf3_rsample_bwd_outer_workspace(int64_t n_i, int64_t n_j, int dt
 extern "C" int vmf3_rsample_bwd_outer(const void* loc, const void* scale, const void* u, const void* eps,
                                       const void* grad_z, const void* grad_kappa, void* dloc, void* dscale,
                                       int64_t n_i, int64_t n_j, void* workspace, int64_t workspace_bytes, int flags,
-                                      int dtype, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                      int dtype, uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                                       vmf_stream_t stream) {
   VMF_RANGE("vmf3_rsample_bwd_outer");
   VMF_REQUIRE(n_i >= 0 && n_j >= 0, VMF_ERR_BAD_ARG, "vmf3_rsample_bwd_outer: negative size");
@@ -393,7 +393,7 @@ extern "C" int vmf3_rsample_bwd_outer(const void* loc, const void* scale, const 
   VMF_REQUIRE(n_i > 0 && n_j > 0, VMF_ERR_UNSUPPORTED, "vmf3_rsample_bwd_outer: an empty dimension next to a non-empty "
               "one (zero-fill the gradients instead)");
   VMF_REQUIRE(loc && scale && grad_z && dloc && dscale, VMF_ERR_BAD_ARG, "vmf3_rsample_bwd_outer: null pointer");
-  V3Call c = make_call(loc, scale, u, eps, flags, dtype, seed, offset, offset_dev, stream);
+  V3Call c = make_call(loc, scale, u, eps, flags, dtype, row0, seed, offset, offset_dev, stream);
   c.gz = grad_z; c.gkappa = grad_kappa; c.dloc = dloc; c.dscale = dscale;
   int rc = vmf3_bwd_outer(c, n_i, n_j, workspace, workspace_bytes);
   if (rc) return rc;
@@ -423,14 +423,14 @@ __global__ __launch_bounds__(256) void vmf3_w_kernel(const T* __restrict__ scale
 }
 
 extern "C" int vmf3_sample_w_fwd(const void* scale, const void* u, void* w, int64_t n, int64_t n_scale, int dtype,
-                                 uint64_t seed, uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream) {
+                                 uint64_t row0, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, vmf_stream_t stream) {
   VMF_RANGE("vmf3_sample_w_fwd");
   VMF_REQUIRE(n >= 0 && n_scale >= 0, VMF_ERR_BAD_ARG, "vmf3_sample_w_fwd: negative size");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(n_scale > 0 && n % n_scale == 0, VMF_ERR_BAD_ARG, "vmf3_sample_w_fwd: n %lld does not tile n_scale %lld",
               (long long)n, (long long)n_scale);
   VMF_REQUIRE(scale && w, VMF_ERR_BAD_ARG, "vmf3_sample_w_fwd: null pointer");
-  PhiloxArg key = make_philox_arg(seed, offset, offset_dev);
+  PhiloxArg key = make_philox_arg(seed, offset, offset_dev, row0);
   int grid = vmf_grid_for(n, 256);
   // fp32 runs the arithmetic of the fp32 rsample kernels (hardware transcendentals), so both give the same w
   if (dtype == VMF_F32)
@@ -445,14 +445,14 @@ extern "C" int vmf3_sample_w_fwd(const void* scale, const void* u, void* w, int6
 }
 
 extern "C" int vmf3_sample_w_bwd(const void* scale, const void* u, const void* grad_w, void* dscale_rows, int64_t n,
-                                 int64_t n_scale, int dtype, uint64_t seed, uint64_t offset,
+                                 int64_t n_scale, int dtype, uint64_t row0, uint64_t seed, uint64_t offset,
                                  const uint64_t* offset_dev, vmf_stream_t stream) {
   VMF_RANGE("vmf3_sample_w_bwd");
   VMF_REQUIRE(n >= 0 && n_scale >= 0, VMF_ERR_BAD_ARG, "vmf3_sample_w_bwd: negative size");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(n_scale > 0 && n % n_scale == 0, VMF_ERR_BAD_ARG, "vmf3_sample_w_bwd: n does not tile n_scale");
   VMF_REQUIRE(scale && grad_w && dscale_rows, VMF_ERR_BAD_ARG, "vmf3_sample_w_bwd: null pointer");
-  PhiloxArg key = make_philox_arg(seed, offset, offset_dev);
+  PhiloxArg key = make_philox_arg(seed, offset, offset_dev, row0);
   int grid = vmf_grid_for(n, 256);
   if (dtype == VMF_F32)
     hipLaunchKernelGGL((vmf3_w_kernel<float, MFast, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,

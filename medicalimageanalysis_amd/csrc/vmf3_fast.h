@@ -40,11 +40,11 @@ __device__ __forceinline__ void v3_eps_of(const U4& r, T e[3]) {
 template <typename T>
 __device__ __forceinline__ T v3_draw_u(const T* u, int64_t wi, PhiloxKey key) {
   if (u) return u[wi];
-  return u01<T>(philox4x32_10((uint64_t)wi, 0u, key).x);
+  return u01<T>(philox4x32_10(key.i0 + (uint64_t)wi, 0u, key).x);
 }
 template <typename T>
 __device__ __forceinline__ void v3_philox_eps(int64_t ei, PhiloxKey key, T e[3]) {
-  v3_eps_of<T>(philox4x32_10((uint64_t)ei, 0u, key), e);
+  v3_eps_of<T>(philox4x32_10(key.i0 + (uint64_t)ei, 0u, key), e);
 }
 template <typename T>
 __device__ __forceinline__ void v3_draw_eps(const T* eps, int64_t ei, PhiloxKey key, T e[3]) {
@@ -62,7 +62,7 @@ __device__ __forceinline__ void v3_draw_row(const T* u, const T* eps, int64_t ro
     e[0] = eps[3 * row]; e[1] = eps[3 * row + 1]; e[2] = eps[3 * row + 2];
     return;
   }
-  const U4 r = philox4x32_10((uint64_t)row, 0u, key);
+  const U4 r = philox4x32_10(key.i0 + (uint64_t)row, 0u, key);
   *uq = u ? u[row] : u01<T>(r.x);
   if (eps) {
     e[0] = eps[3 * row]; e[1] = eps[3 * row + 1]; e[2] = eps[3 * row + 2];

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void vmf3_rows_kernel(const T* __restrict__ lo
       kap[q] = softplus ? v3_softplus_kappa<T, MP>(k[q], &sig) : k[q];
       T uq = uu[q];
       if (!u || !eps) {  // in-kernel noise: one Philox call per row serves u and the eps row
-        const U4 pr = philox4x32_10((uint64_t)row, 0u, key);
+        const U4 pr = philox4x32_10(key.i0 + (uint64_t)row, 0u, key);
         if (!u) uq = u01<T>(pr.x);
         if (!eps) v3_eps_of<T>(pr, &e[3 * q]);
       }

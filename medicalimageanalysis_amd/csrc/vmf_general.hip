@@ -801,6 +801,11 @@ constexpr int CF_STEPS = CF_TILE / 128;
 #ifndef VMF_CF_XCD
 #define VMF_CF_XCD 1
 #endif
+// tiles per wave; beyond one, the next tile's loads are issued before the current tile is computed
+#ifndef VMF_CF_PIPE
+#define VMF_CF_PIPE 1
+#endif
+constexpr int CF_PIPE = VMF_CF_PIPE;
 #ifndef VMF_CF_NT
 #define VMF_CF_NT 1
 #endif
@@ -810,19 +815,19 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {  // set bi
 // OPTS: any of softplus / normalize / kappa_out / w_out / omw_out / accept_idx / logp is in use.  FULL: the tile has all
 // its CF_TILE rows (the ragged last tile runs the same code with guarded accesses; a separate instantiation, so that the
 // full tiles' loads and their waits are straight-line code the compiler can count).
-template <bool OPTS, bool FULL>
-__device__ __forceinline__ void circle_tile(const FwdParams<float>& p, const PhiloxKey key, float* const park,
-                                            uint16_t* const queue, const int64_t tile0, const int ntile, const int lane) {
+struct CircleRegs {
+  f32x2 kap[CF_STEPS];
+  f32x4 mu[CF_STEPS];
+};
+// every load of a tile
+template <bool FULL>
+__device__ __forceinline__ void circle_load(CircleRegs& r, const FwdParams<float>& p, const int64_t tile0,
+                                            const int ntile, const int lane) {
   constexpr bool full = FULL;
   const float* const kap_t = p.kappa + tile0;
   const float* const mu_t = p.mu + 2 * tile0;
-  float* const z_t = p.z + 2 * tile0;
-  const uint64_t grow0 = p.row0 + (uint64_t)tile0;  // even: the launch code sends odd row offsets to the other kernel
-  const bool normalize = OPTS && p.normalize != 0;
-
-  // ---- every load of the tile ----
-  f32x2 kap[CF_STEPS];
-  f32x4 mu[CF_STEPS];
+  f32x2(&kap)[CF_STEPS] = r.kap;
+  f32x4(&mu)[CF_STEPS] = r.mu;
   if (full) {
 #pragma unroll
     for (int s = 0; s < CF_STEPS; ++s)
@@ -844,6 +849,21 @@ __device__ __forceinline__ void circle_tile(const FwdParams<float>& p, const Phi
       mu[s] = f32x4{a.x, a.y, b.x, b.y};
     }
   }
+}
+// PF: the wave has another full tile after this one, at rows next0 ...: its kappa loads are issued once phase 1a has
+// consumed this tile's (into the same registers), its mu loads step by step as phase 2 releases this tile's -- so a wave
+// always has loads in flight while it computes, at no cost in registers
+template <bool OPTS, bool FULL, bool PF>
+__device__ __forceinline__ void circle_compute(CircleRegs& r, const FwdParams<float>& p, const PhiloxKey key,
+                                               float* const park, uint16_t* const queue, const int64_t tile0,
+                                               const int ntile, const int lane, const int64_t next0 = 0) {
+  static_assert(!PF || (FULL && !OPTS), "prefetch: full tiles of the plain instantiation only");
+  constexpr bool full = FULL;
+  float* const z_t = p.z + 2 * tile0;
+  const uint64_t grow0 = p.row0 + (uint64_t)tile0;  // even: the launch code sends odd row offsets to the other kernel
+  const bool normalize = OPTS && p.normalize != 0;
+  f32x2(&kap)[CF_STEPS] = r.kap;
+  f32x4(&mu)[CF_STEPS] = r.mu;
 
   // ---- phase 1a: the first proposal of every row ----
   int qn = 0;  // rows waiting for further proposals (wave-uniform)
@@ -895,6 +915,11 @@ __device__ __forceinline__ void circle_tile(const FwdParams<float>& p, const Phi
         if (p.accept_idx) p.accept_idx[tile0 + rA + 1] = 0;
       }
     }
+  }
+  if (PF) {
+#pragma unroll
+    for (int s = 0; s < CF_STEPS; ++s)
+      kap[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p.kappa + next0) + 64 * s + lane);
   }
   wave_lds_sync();
 
@@ -957,6 +982,7 @@ __device__ __forceinline__ void circle_tile(const FwdParams<float>& p, const Phi
     circle_compose<float>(mu[s].z, mu[s].w, pk.z, pk.w, normalize, &zB0, &zB1, &mzB);
     if (full) {
       store_nt(f32x4{zA0, zA1, zB0, zB1}, z_t + 4 * (64 * s + lane));
+      if (PF) mu[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.mu + 2 * next0) + 64 * s + lane);
     } else {
       if (rA < ntile) *reinterpret_cast<f32x2*>(z_t + 2 * rA) = f32x2{zA0, zA1};
       if (rA + 1 < ntile) *reinterpret_cast<f32x2*>(z_t + 2 * rA + 2) = f32x2{zB0, zB1};
@@ -967,23 +993,53 @@ __device__ __forceinline__ void circle_tile(const FwdParams<float>& p, const Phi
       if (rA + 1 < ntile) p.logp[tile0 + rA + 1] = vfma(kB, mzB, vmf_log_norm_circle_f32(kB));
     }
   }
+  if (CF_PIPE > 1) wave_lds_sync();  // the next tile of this wave reuses the slab and the queue
 }
 template <bool OPTS>
 __global__ __launch_bounds__(WAVES * 64, VMF_CF_WAVES_PER_SIMD) void vmf_circle_fwd_kernel(FwdParams<float> p) {
   __shared__ __align__(16) float s_park[WAVES][2 * CF_TILE];
   __shared__ uint16_t s_queue[WAVES][CF_TILE];
   const PhiloxKey key = philox_resolve(p.ka);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  // the wave index as a scalar: tile bases then live in scalar registers and every access is base + lane offset
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #if VMF_CF_XCD
   const uint32_t bid = xcd_block(blockIdx.x, gridDim.x);
 #else
   const uint32_t bid = blockIdx.x;
 #endif
-  const int64_t tile0 = ((int64_t)bid * WAVES + wave) * CF_TILE;  // wave-uniform
+  constexpr int K = CF_PIPE;
+  const int64_t tile0 = ((int64_t)bid * WAVES + wave) * (K * CF_TILE);  // wave-uniform
   const int64_t left = p.n - tile0;
   if (left <= 0) return;  // the kernel has no workgroup barrier
-  if (left >= CF_TILE) circle_tile<OPTS, true>(p, key, s_park[wave], s_queue[wave], tile0, CF_TILE, lane);
-  else circle_tile<OPTS, false>(p, key, s_park[wave], s_queue[wave], tile0, (int)left, lane);
+  float* const park = s_park[wave];
+  uint16_t* const queue = s_queue[wave];
+  const int nfull = left >= (int64_t)K * CF_TILE ? K : (int)(left / CF_TILE);  // full tiles of this wave
+  CircleRegs r;
+  if (K > 1 && !OPTS && nfull == K) {
+    // K full tiles as straight-line code: each tile's loads are issued while the tile before it computes
+    circle_load<true>(r, p, tile0, CF_TILE, lane);
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      if (i + 1 < K)
+        circle_compute<false, true, true>(r, p, key, park, queue, tile0 + (int64_t)i * CF_TILE, CF_TILE, lane,
+                                          tile0 + (int64_t)(i + 1) * CF_TILE);
+      else
+        circle_compute<false, true, false>(r, p, key, park, queue, tile0 + (int64_t)i * CF_TILE, CF_TILE, lane);
+    }
+    return;
+  } else {
+#pragma unroll 1
+    for (int i = 0; i < nfull; ++i) {
+      circle_load<true>(r, p, tile0 + (int64_t)i * CF_TILE, CF_TILE, lane);
+      circle_compute<OPTS, true, false>(r, p, key, park, queue, tile0 + (int64_t)i * CF_TILE, CF_TILE, lane);
+    }
+  }
+  const int64_t rem = left - (int64_t)nfull * CF_TILE;
+  if (nfull < K && rem > 0) {  // the ragged last tile
+    circle_load<false>(r, p, tile0 + (int64_t)nfull * CF_TILE, (int)rem, lane);
+    circle_compute<OPTS, false, false>(r, p, key, park, queue, tile0 + (int64_t)nfull * CF_TILE, (int)rem, lane);
+  }
 }
 
 // Backward: one pass over (grad_z, mu) rows; normals regenerated from the counters unless given.
@@ -1429,7 +1485,7 @@ static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
     // dense aligned circles whose pairs of rows (2p, 2p+1) in the GLOBAL numbering are 16-byte units: two rows per lane
     if (pair_ok && mu_stride == 2 && kappa_stride == 1 && (row0 & 1u) == 0 && aligned16(mu) && aligned16(z) &&
         ((uintptr_t)kappa & 7u) == 0) {
-      const int64_t nt = (n + CF_TILE - 1) / CF_TILE;
+      const int64_t nt = (n + CF_PIPE * CF_TILE - 1) / (CF_PIPE * CF_TILE);
       const int64_t nb = (nt + WAVES - 1) / WAVES;
       VMF_REQUIRE(nb <= 0x7fffffff, VMF_ERR_UNSUPPORTED, "n=%lld rows need more than 2^31 workgroups", (long long)n);
       const bool opts = p.softplus || p.normalize || kappa_out || w_out || omw_out || accept_idx || logp_out;

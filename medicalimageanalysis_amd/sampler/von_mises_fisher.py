@@ -99,7 +99,7 @@ class _VMF3RSample(torch.autograd.Function):
     are differentiable and one backward launch serves both (no separate softplus / add passes in either direction)."""
 
     @staticmethod
-    def forward(ctx, loc, scale, u, eps, plan, seed, offset, offset_dev=None, softplus=False):
+    def forward(ctx, loc, scale, u, eps, plan, seed, offset, offset_dev=None, softplus=False, row0=0):
         dev = _lib.require_hip(loc, scale, u, eps)
         locc, scalec = loc.detach().contiguous(), scale.detach().contiguous()
         uc = None if u is None else u.contiguous()
@@ -111,12 +111,13 @@ class _VMF3RSample(torch.autograd.Function):
             with _lib.on_device(dev):
                 rc = _lib.lib().vmf3_rsample_fwd(
                     _lib.ptr(locc), _lib.ptr(scalec), _lib.ptr(uc), _lib.ptr(epsc), _lib.ptr(z), None, _lib.ptr(kappa),
-                    *plan["c_args"], flags, _lib.dtype_code(loc), seed, offset, _lib.ptr(offset_dev), _lib.stream_ptr(dev))
+                    *plan["c_args"], flags, _lib.dtype_code(loc), row0, seed, offset, _lib.ptr(offset_dev),
+                    _lib.stream_ptr(dev))
             _lib.check(rc, "vmf3_rsample_fwd")
         elif softplus and kappa.numel():
             kappa = torch.nn.functional.softplus(scalec) + 1  # nothing to sample: no kernel ran
         ctx.save_for_backward(locc, scalec, uc, epsc)
-        ctx.plan, ctx.seed, ctx.offset, ctx.offset_dev, ctx.flags = plan, seed, offset, offset_dev, flags
+        ctx.plan, ctx.seed, ctx.offset, ctx.offset_dev, ctx.flags, ctx.row0 = plan, seed, offset, offset_dev, flags, row0
         ctx.loc_shape, ctx.scale_shape = loc.shape, scale.shape
         return (z, kappa.view(scale.shape)) if softplus else z
 
@@ -131,7 +132,8 @@ class _VMF3RSample(torch.autograd.Function):
         odims, n_out = plan["odims"], _numel(plan["odims"])
         n_loc, n_scale = locc.numel() // 3, scalec.numel()
         kind, n_i, n_j = _plan_kind(plan) if n_out else (_lib.KIND_GENERAL, 0, 0)
-        common = (flags, _lib.dtype_code(locc), ctx.seed, ctx.offset, _lib.ptr(ctx.offset_dev), _lib.stream_ptr(dev))
+        common = (flags, _lib.dtype_code(locc), ctx.row0, ctx.seed, ctx.offset, _lib.ptr(ctx.offset_dev),
+                  _lib.stream_ptr(dev))
         if kind == _lib.KIND_OUTER:
             # the (B, 1)-scale broadcast: one pass over grad z, sums over i and over j inside the library (fixed order)
             dloc, dscale = torch.empty_like(locc), torch.empty_like(scalec)
@@ -146,7 +148,7 @@ class _VMF3RSample(torch.autograd.Function):
                                                 _lib.ptr(gzc), _lib.ptr(gkc), _lib.ptr(dloc), _lib.ptr(dscale), n_i, n_j,
                                                 _lib.ptr(ws), ws.numel() * 8, *common)
             _lib.check(rc, "vmf3_rsample_bwd_outer")
-            return (dloc.reshape(ctx.loc_shape), dscale.reshape(ctx.scale_shape)) + (None,) * 7
+            return (dloc.reshape(ctx.loc_shape), dscale.reshape(ctx.scale_shape)) + (None,) * 8
         shared = not (n_loc == n_out and n_scale == n_out)
         # Any other broadcast with rows that share a loc row / scale element (sample shapes ...): by default the kernel
         # writes one gradient row per output row and torch sums them (same bits every run); VMF_ATOMIC_BWD=1 lets the
@@ -173,15 +175,16 @@ class _VMF3RSample(torch.autograd.Function):
         dscale = dscale.reshape(ctx.scale_shape)
         if gkc is not None and not in_kernel_gk:  # rare shapes: the kappa output's own chain rule with torch ops
             dscale = dscale + gkc.reshape(ctx.scale_shape) * torch.sigmoid(scalec.reshape(ctx.scale_shape))
-        return (dloc.reshape(ctx.loc_shape), dscale) + (None,) * 7
+        return (dloc.reshape(ctx.loc_shape), dscale) + (None,) * 8
 
 
-def vmf3_rsample_from_heads(loc, scale_raw, sample_shape=torch.Size()):
+def vmf3_rsample_from_heads(loc, scale_raw, sample_shape=torch.Size(), row_offset=0):
     """(z, kappa) straight from the two encoder heads: loc is the un-normalised output of the mean head (B, 3),
     scale_raw the raw output of the concentration head; kappa = softplus(scale_raw) + 1 (model/spherical_vae.py:68-72,
     model/torus_vae.py:101-105, CNN_experiment/circular_VAE.py:47-51) is evaluated inside the sampler kernel and
     returned next to z = VonMisesFisher3D(loc, kappa).rsample(sample_shape).  Same noise as rsample() (u then eps from
-    torch's generator, or the in-kernel streams when VMF_RNG=philox); both outputs carry gradients to both heads."""
+    torch's generator, or the in-kernel streams when VMF_RNG=philox, numbered from the global `row_offset`); both outputs
+    carry gradients to both heads."""
     sample_shape = torch.Size(sample_shape)
     assert loc.shape[-1] == 3, "This simple version o"
     scale_raw = scale_raw if scale_raw.dtype == loc.dtype else scale_raw.to(loc.dtype)
@@ -194,40 +197,40 @@ def vmf3_rsample_from_heads(loc, scale_raw, sample_shape=torch.Size()):
     else:
         u = eps = None
         seed, offset, offset_dev = rng.default_generator.ticket(loc.device)
-    return _VMF3RSample.apply(loc, scale_raw, u, eps, plan, seed, offset, offset_dev, True)
+    return _VMF3RSample.apply(loc, scale_raw, u, eps, plan, seed, offset, offset_dev, True, int(row_offset))
 
 
 class _VMF3SampleW(torch.autograd.Function):
     """w = 1 + logsumexp([log u, log(1-u) - 2k]) / k elementwise over sample_shape + scale.shape, gradient to scale"""
 
     @staticmethod
-    def forward(ctx, scale, u, w_shape, seed, offset, offset_dev=None):
+    def forward(ctx, scale, u, w_shape, seed, offset, offset_dev=None, row0=0):
         dev = _lib.require_hip(scale, u)
         sc = scale.detach().contiguous()
         uc = None if u is None else u.to(sc.dtype).contiguous()
         w = torch.empty(w_shape, device=dev, dtype=sc.dtype)
         with _lib.on_device(dev):
             rc = _lib.lib().vmf3_sample_w_fwd(_lib.ptr(sc), _lib.ptr(uc), _lib.ptr(w), w.numel(), sc.numel(),
-                                              _lib.dtype_code(sc), seed, offset, _lib.ptr(offset_dev),
+                                              _lib.dtype_code(sc), row0, seed, offset, _lib.ptr(offset_dev),
                                               _lib.stream_ptr(dev))
         _lib.check(rc, "vmf3_sample_w_fwd")
         ctx.save_for_backward(sc, uc)
-        ctx.meta = (seed, offset, offset_dev, tuple(scale.shape))
+        ctx.meta = (row0, seed, offset, offset_dev, tuple(scale.shape))
         return w
 
     @staticmethod
     def backward(ctx, gw):
         sc, uc = ctx.saved_tensors
-        seed, offset, offset_dev, sshape = ctx.meta
+        row0, seed, offset, offset_dev, sshape = ctx.meta
         dev = sc.device
         g = gw.to(sc.dtype).contiguous()
         rows = torch.empty_like(g)
         with _lib.on_device(dev):
             rc = _lib.lib().vmf3_sample_w_bwd(_lib.ptr(sc), _lib.ptr(uc), _lib.ptr(g), _lib.ptr(rows), g.numel(),
-                                              sc.numel(), _lib.dtype_code(sc), seed, offset, _lib.ptr(offset_dev),
+                                              sc.numel(), _lib.dtype_code(sc), row0, seed, offset, _lib.ptr(offset_dev),
                                               _lib.stream_ptr(dev))
         _lib.check(rc, "vmf3_sample_w_bwd")
-        return rows.reshape((-1,) + sshape).sum(0), None, None, None, None, None
+        return rows.reshape((-1,) + sshape).sum(0), None, None, None, None, None, None
 
 
 class VonMisesFisher3D(Distribution):
@@ -240,6 +243,10 @@ class VonMisesFisher3D(Distribution):
         Mean direction; normalised as loc / (||loc|| + 1e-5) like the reference (:30).
     scale : tensor (...) -- or (..., 1), which broadcasts rsample() to (B, B, 3) exactly as the reference does.
         Concentration kappa > 0.
+    row_offset : int, keyword only (not in the reference, which runs on one device)
+        Global index of this tensor's first row when the batch is sharded over ranks: with VMF_RNG=philox the in-kernel
+        noise of row i is keyed by row_offset + i, so a rank that holds rows [a, b) and passes row_offset=a draws exactly
+        the rows the unsharded call draws ((B,) and (B, 1) scale).  Ignored with torch noise.
     """
 
     arg_constraints = {
@@ -249,8 +256,9 @@ class VonMisesFisher3D(Distribution):
     support = constraints.real  # type: ignore
     has_rsample = True
 
-    def __init__(self, loc, scale, validate_args=None):
+    def __init__(self, loc, scale, validate_args=None, *, row_offset=0):
         assert loc.shape[-1] == 3, "This simple version o"
+        self.row_offset = int(row_offset)
         self._loc_raw = loc
         self._loc_n = None
         self.scale = scale
@@ -287,7 +295,7 @@ class VonMisesFisher3D(Distribution):
         else:
             u = None
             seed, offset, offset_dev = rng.default_generator.ticket(self.scale.device)
-        return _VMF3SampleW.apply(self.scale, u, tuple(shape), seed, offset, offset_dev)
+        return _VMF3SampleW.apply(self.scale, u, tuple(shape), seed, offset, offset_dev, self.row_offset)
 
     def rsample(self, sample_shape=torch.Size()):
         """Reparameterised sample of shape broadcast(sample_shape + scale.shape, sample_shape + batch_shape) + (3,)
@@ -305,7 +313,7 @@ class VonMisesFisher3D(Distribution):
         else:
             u = eps = None
             seed, offset, offset_dev = rng.default_generator.ticket(loc.device)
-        return _VMF3RSample.apply(loc, scale, u, eps, plan, seed, offset, offset_dev)
+        return _VMF3RSample.apply(loc, scale, u, eps, plan, seed, offset, offset_dev, False, self.row_offset)
 
     def rsample_with_noise(self, u, eps, sample_shape=torch.Size()):
         """rsample with the caller's noise: u of shape sample_shape + scale.shape (uniform), eps of shape

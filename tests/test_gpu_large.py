@@ -60,7 +60,7 @@ def _vmf3_fwd(loc, scale, u, eps, z, w_out):
     plan = vmf3_broadcast_plan(tuple(loc.shape), tuple(scale.shape))
     pa = [_lib.i64_array(plan[k]) for k in ("odims", "w_str", "k_str", "l_str", "e_str")]
     rc = _lib.lib().vmf3_rsample_fwd(_lib.ptr(loc), _lib.ptr(scale), _lib.ptr(u), _lib.ptr(eps), _lib.ptr(z), _lib.ptr(w_out),
-                                     None, len(plan["odims"]), *pa, 0, _lib.VMF_F32, 9, 0, None, _lib.stream_ptr(DEV))
+                                     None, len(plan["odims"]), *pa, 0, _lib.VMF_F32, 0, 9, 0, None, _lib.stream_ptr(DEV))
     assert rc == 0, _lib.lib().vmf_last_error_string()
     return pa, len(plan["odims"])
 
@@ -157,7 +157,7 @@ def test_vmf3_outer_beyond_2_to_32_elements_forward_and_backward():
         dloc, dk = torch.empty_like(loc), torch.empty_like(kap_b)
         rc = lib.vmf3_rsample_bwd_outer(_lib.ptr(loc), _lib.ptr(kap_b), _lib.ptr(u_b), _lib.ptr(eps), _lib.ptr(gz_b), None,
                                         _lib.ptr(dloc), _lib.ptr(dk), kap_b.numel(), n_j, _lib.ptr(ws), ws.numel() * 8, 0,
-                                        _lib.VMF_F32, 9, 0, None, sp)
+                                        _lib.VMF_F32, 0, 9, 0, None, sp)
         assert rc == 0, lib.vmf_last_error_string()
         torch.cuda.synchronize()
         return dloc, dk

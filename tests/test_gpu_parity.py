@@ -107,7 +107,7 @@ def close_vmf3(z, z_ref, tag, loc, scale, u, eps, ss=(), name="vmf3"):
 
 def test_library_loaded_is_in_tree():
     assert os.path.dirname(_lib.library_path()).endswith("medicalimageanalysis_amd")
-    assert _lib.lib().vmf_version() == 131
+    assert _lib.lib().vmf_version() == 140
 
 
 # ---- VonMisesFisher3D ---------------------------------------------------------------------------------------
@@ -1146,6 +1146,58 @@ def test_general_softplus_fold_matches_torch_softplus(tag, m):
         np.testing.assert_allclose(ka_, kb_, rtol=5e-3, atol=5e-3 * np.abs(kb_).max())
 
 
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_vmf3_in_kernel_noise_is_keyed_by_the_global_row(tag):
+    """VonMisesFisher3D with VMF_RNG=philox: a rank that holds rows [a, b) of the batch and passes row_offset=a draws the
+    rows the unsharded call draws, bit for bit -- for the (B,) concentration (rows kind), for the (B, 1) concentration
+    whose sample is the (B, B, 3) outer product (a shard of both index ranges = a block of the full result), for
+    _sample_w3, and for the backward passes, which regenerate the noise from the same counters."""
+    os.environ["VMF_RNG"] = "philox"
+    try:
+        dt = TD[tag]
+        g = torch.Generator(device=DEV).manual_seed(31)
+        B, a, b = 1500, 517, 1301
+        loc = torch.randn(B, 3, device=DEV, dtype=dt, generator=g)
+        kap = torch.rand(B, device=DEV, dtype=dt, generator=g) * 80 + 0.5
+
+        def draw(lo, hi, outer):
+            rng.default_generator.set_state({"seed": 77, "offset": 5})
+            l_ = loc[lo:hi].clone().requires_grad_()
+            k_ = (kap[lo:hi, None] if outer else kap[lo:hi]).clone().requires_grad_()
+            q = VonMisesFisher3D(l_, k_, validate_args=False, row_offset=lo)
+            z = q.rsample()
+            c = torch.cos(torch.arange(z.numel(), device=DEV, dtype=dt)).view_as(z)  # the same weights for every call
+            return z, l_, k_, c
+
+        for outer in (False, True):
+            z, l_, k_, c = draw(0, B, outer)
+            zs, ls, ks, _ = draw(a, b, outer)
+            want = z[a:b, a:b] if outer else z[a:b]
+            assert torch.equal(zs, want), outer
+            # backward with the full call's weights on the shard's block; the other blocks get zero weight in the full
+            # call, so both see the same gradient (the fp sums run over the same terms plus exact zeros)
+            cs = (c[a:b, a:b] if outer else c[a:b]).contiguous()
+            (zs * cs).sum().backward()
+            mask = torch.zeros_like(c)
+            if outer:
+                mask[a:b, a:b] = 1
+            else:
+                mask[a:b] = 1
+            (z * (c * mask)).sum().backward()
+            rt = 1e-12 if tag == "f64" else 2e-5
+            np.testing.assert_allclose(N(ls.grad), N(l_.grad[a:b]), rtol=rt, atol=rt * float(l_.grad.abs().max()))
+            np.testing.assert_allclose(N(ks.grad), N(k_.grad[a:b]), rtol=rt, atol=rt * float(k_.grad.abs().max()))
+            if not outer:   # rows kind: one term per gradient element, so the bits agree as well
+                assert torch.equal(ls.grad, l_.grad[a:b]) and torch.equal(ks.grad, k_.grad[a:b])
+        rng.default_generator.set_state({"seed": 77, "offset": 9})
+        w = VonMisesFisher3D(loc, kap, validate_args=False)._sample_w3(torch.Size())
+        rng.default_generator.set_state({"seed": 77, "offset": 9})
+        ws = VonMisesFisher3D(loc[a:b], kap[a:b], validate_args=False, row_offset=a)._sample_w3(torch.Size())
+        assert torch.equal(ws, w[a:b])
+    finally:
+        os.environ.pop("VMF_RNG")
+
+
 @pytest.mark.parametrize("max_prop", [1, 2, 3, 64])
 @pytest.mark.parametrize("opts", [False, True])
 def test_circle_pair_kernel_and_row_kernel_give_the_same_bits(opts, max_prop):
@@ -1910,7 +1962,7 @@ def test_kernels_write_nothing_outside_their_outputs(pad):
         wb, w = _guarded(ni, pad)
         kb, ko = _guarded(ni, pad)
         rc = lib.vmf3_rsample_fwd(_lib.ptr(loc), _lib.ptr(kap), None, None, _lib.ptr(z), _lib.ptr(w), _lib.ptr(ko),
-                                  *plan["c_args"], 0, _lib.VMF_F32, 3, 0, None, sp)
+                                  *plan["c_args"], 0, _lib.VMF_F32, 0, 3, 0, None, sp)
         assert rc == 0, lib.vmf_last_error_string()
         torch.cuda.synchronize()
         assert _margins_intact(zb, nz, pad) and _margins_intact(wb, ni, pad) and _margins_intact(kb, ni, pad), (ni, nj)
@@ -1924,13 +1976,13 @@ def test_kernels_write_nothing_outside_their_outputs(pad):
             nws = (nb.value + 7) // 8
             wsb, ws = _guarded(nws + 2, 2, torch.float64)  # 16-byte aligned whatever `pad` is
             rc = lib.vmf3_rsample_bwd_outer(_lib.ptr(loc), _lib.ptr(kap), None, None, _lib.ptr(gz), None, _lib.ptr(dl),
-                                            _lib.ptr(dk), ni, nj, _lib.ptr(ws), nws * 8, 0, _lib.VMF_F32, 3, 0, None, sp)
+                                            _lib.ptr(dk), ni, nj, _lib.ptr(ws), nws * 8, 0, _lib.VMF_F32, 0, 3, 0, None, sp)
             assert rc == 0, lib.vmf_last_error_string()
             torch.cuda.synchronize()
             assert _margins_intact(wsb, nws + 2, 2)
         else:
             rc = lib.vmf3_rsample_bwd(_lib.ptr(loc), _lib.ptr(kap), None, None, _lib.ptr(gz), None, _lib.ptr(dl), _lib.ptr(dk),
-                                      nj, ni, *plan["c_args"], 0, _lib.VMF_F32, 3, 0, None, sp)
+                                      nj, ni, *plan["c_args"], 0, _lib.VMF_F32, 0, 3, 0, None, sp)
             assert rc == 0, lib.vmf_last_error_string()
             torch.cuda.synchronize()
         assert _margins_intact(dlb, nj * 3, pad) and _margins_intact(dkb, ni, pad), (ni, nj)

@@ -3,6 +3,7 @@
 import ctypes as C
 import os
 import re
+import socket
 import subprocess
 import sys
 
@@ -24,7 +25,7 @@ def test_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(h, name), name
     lib = _lib.lib()
-    assert lib.vmf_version() == 131
+    assert lib.vmf_version() == 140
     # argument errors are reported without touching a GPU
     assert lib.vmf_rsample_fwd(None, 64, None, 1, None, None, None, None, None, None, -1, 64, None, None, 0, None, 64, 0, 0, 0, None, 0,
                                0, None) == -1
@@ -97,7 +98,7 @@ def test_outer_backward_workspace_size_is_reported_without_a_gpu():
     assert lib.vmf3_rsample_bwd_outer_workspace(-1, 4, _lib.VMF_F32, C.byref(nb)) == -1
     # too small a workspace is refused before anything is launched
     rc = lib.vmf3_rsample_bwd_outer(C.c_void_p(16), C.c_void_p(16), None, None, C.c_void_p(16), None, C.c_void_p(16),
-                                    C.c_void_p(16), 64, 64, C.c_void_p(16), 8, 0, 0, 0, 0, None, None)
+                                    C.c_void_p(16), 64, 64, C.c_void_p(16), 8, 0, 0, 0, 0, 0, None, None)
     assert rc == -1 and b"workspace" in lib.vmf_last_error_string()
 
 
@@ -327,6 +328,34 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["rehearsal"] is True and rec["steps"] == 3
     assert len(rec["kernel_ms_per_rank"]) == 2
     assert rec["allreduce"]["count_seen"] == 2 * 4096      # the packed scalars really went through the collective
+
+
+def test_bench_rehearsal_with_eight_ranks_and_under_a_launcher():
+    """the shape of the round-end scaling run, without GPUs: eight ranks started by bench.py itself, and two ranks
+    started by `python -m torch.distributed.run` exactly as the driver starts them; every rank reports its own identity
+    in the line (on GPUs: ordinal, PCI address, uuid -- here the process ids, which must all differ)."""
+    import json
+    out = _run_bench("--gpus", "8", "--rows", "1024", "--cpu-rows", "0", "--steps", "2", "--warmup", "1",
+                     "--with-allreduce", "--rehearse")
+    assert out.returncode == 0, out.stderr
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["n_gpus"] == 8 and rec["ranks_seen"] == 8 and len(rec["kernel_ms_per_rank"]) == 8
+    assert [d["rank"] for d in rec["devices"]] == list(range(8))
+    assert len({d["pid"] for d in rec["devices"]}) == 8
+    assert rec["allreduce"]["count_seen"] == 8 * 1024
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-rows", "0", "--rehearse"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and [d["local_rank"] for d in rec["devices"]] == [0, 1]
 
 
 def test_bench_fails_when_a_rank_fails():

@@ -61,7 +61,7 @@ def main():
 
         def f():
             rc = lib.vmf3_rsample_fwd(_lib.ptr(loc), _lib.ptr(kap), _lib.ptr(u), _lib.ptr(eps), _lib.ptr(z), None, None, nd,
-                                      *pa, 0, _lib.VMF_F32, 1, 0, None, sp)
+                                      *pa, 0, _lib.VMF_F32, 0, 1, 0, None, sp)
             assert rc == 0, lib.vmf_last_error_string()
         row(f"{name} forward, {'given' if given else 'in-kernel'} noise", timeit(f), fwd_bytes)
         gz = torch.randn_like(z)
@@ -76,13 +76,13 @@ def main():
             def b():
                 rc = lib.vmf3_rsample_bwd_outer(_lib.ptr(loc), _lib.ptr(kap), _lib.ptr(u), _lib.ptr(eps), _lib.ptr(gz), None,
                                                 _lib.ptr(dloc), _lib.ptr(dk), ni.value, nj.value, _lib.ptr(ws),
-                                                ws.numel() * 8, 0, _lib.VMF_F32, 1, 0, None, sp)
+                                                ws.numel() * 8, 0, _lib.VMF_F32, 0, 1, 0, None, sp)
                 assert rc == 0, lib.vmf_last_error_string()
         else:
             def b():
                 rc = lib.vmf3_rsample_bwd(_lib.ptr(loc), _lib.ptr(kap), _lib.ptr(u), _lib.ptr(eps), _lib.ptr(gz), None,
                                           _lib.ptr(dloc), _lib.ptr(dk), loc.numel() // 3, kap.numel(), nd, *pa, 0,
-                                          _lib.VMF_F32, 1, 0, None, sp)
+                                          _lib.VMF_F32, 0, 1, 0, None, sp)
                 assert rc == 0, lib.vmf_last_error_string()
         tb = timeit(b)
         row(f"{name} backward, {'given' if given else 'regenerated'} noise", tb, bwd_bytes)
