@@ -9,22 +9,24 @@
 // ---- ive ---------------------------------------------------------------------------------------------
 // The reference moves z to the host, calls scipy (AMOS / cephes, double internally for either dtype) and
 // copies the result back (sampler/ive.py:18-28).  Here each lane evaluates in double and rounds once to T.
-template <typename T>
+// The order's coefficient tables (IveTab) travel as kernel arguments: the kernels read them through scalar loads.
+// KIND / KIND1: the evaluator of the order (and of the order minus one), see ive_kind_of.
+template <typename T, int KIND>
 __global__ __launch_bounds__(256) void ive_fwd_kernel(const T* __restrict__ z, T* __restrict__ out, int64_t n,
-                                                      BesselOrder o) {
+                                                      BesselOrder o, IveTab tab) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    out[i] = (T)ive_eval(o, (double)z[i]);
+    out[i] = (T)ive_eval_kind<KIND>(o, tab, (double)z[i]);
 }
 
-template <typename T>
+template <typename T, int KIND, int KIND1>
 __global__ __launch_bounds__(256) void ive_bwd_kernel(const T* __restrict__ z, const T* __restrict__ gout,
                                                       T* __restrict__ gz, int64_t n, BesselOrder o,
-                                                      BesselOrder om1, T v) {
+                                                      BesselOrder om1, IveTab tab, IveTab tabm1, T v) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     T zi = z[i];
-    T a = (T)ive_eval(o, (double)zi), b = (T)ive_eval(om1, (double)zi);
+    T a = (T)ive_eval_kind<KIND>(o, tab, (double)zi), b = (T)ive_eval_kind<KIND1>(om1, tabm1, (double)zi);
     T zs = M<T>::abs(zi) < (T)1e-8 ? (T)1e-8 : zi;                       // sampler/ive.py:55-56
     T sg = (T)((zi > (T)0) - (zi < (T)0));                               // torch.sign
     gz[i] = gout[i] * (b - (v / zs + sg) * a);                           // :60-62
@@ -58,9 +60,18 @@ extern "C" int vmf_ive_fwd(double v, const void* z, void* out, int64_t n, int dt
   VMF_REQUIRE(z && out, VMF_ERR_BAD_ARG, "vmf_ive_fwd: null pointer");
   // forward call site: i0e / i1e for v == 0 / 1, scipy.special.ive otherwise (sampler/ive.py:21-26)
   BesselOrder o = make_bessel_order(v, !(v == 0.0 || v == 1.0));
+  const IveTab tab = make_ive_tab(o);
   int grid = vmf_grid_for(n, 256);
-  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(ive_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                               (const T*)z, (T*)out, n, o));
+#define VMF_IVE_FWD(K)                                                                                          \
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ive_fwd_kernel<T, K>), dim3(grid), dim3(256), 0, (hipStream_t)stream, \
+                                               (const T*)z, (T*)out, n, o, tab))
+  switch (ive_kind_of(o)) {
+    case IVE_KIND_CHEB: VMF_IVE_FWD(IVE_KIND_CHEB); break;
+    case IVE_KIND_HALF: VMF_IVE_FWD(IVE_KIND_HALF); break;
+    case IVE_KIND_GENERIC: VMF_IVE_FWD(IVE_KIND_GENERIC); break;
+    default: VMF_IVE_FWD(IVE_KIND_SLOW); break;
+  }
+#undef VMF_IVE_FWD
   return vmf_check_launch("vmf_ive_fwd");
 }
 
@@ -73,9 +84,23 @@ extern "C" int vmf_ive_bwd(double v, const void* z, const void* gout, void* gz, 
   // backward call sites (sampler/ive.py:40-48): v == 0 -> (i0e, ive(-1)); v == 1 -> (i1e, i0e); else ive, ive
   BesselOrder o = make_bessel_order(v, !(v == 0.0 || v == 1.0));
   BesselOrder om1 = make_bessel_order(v - 1.0, v != 1.0);
+  const IveTab tab = make_ive_tab(o), tabm1 = make_ive_tab(om1);
   int grid = vmf_grid_for(n, 256);
-  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(ive_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                               (const T*)z, (const T*)gout, (T*)gz, n, o, om1, (T)v));
+#define VMF_IVE_BWD(K, K1)                                                                                     \
+  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ive_bwd_kernel<T, K, K1>), dim3(grid), dim3(256), 0,            \
+                                               (hipStream_t)stream, (const T*)z, (const T*)gout, (T*)gz, n, o, om1, \
+                                               tab, tabm1, (T)v))
+  // the pairs (order, order - 1) that occur: integers (2 -> generic + Chebyshev, beyond: generic twice; 0 and 1:
+  // Chebyshev twice), the half-integers with closed forms, other positive orders above one; anything else (an order
+  // minus one in (-1, 0)) takes the general evaluator for both
+  const int k = ive_kind_of(o), k1 = ive_kind_of(om1);
+  if (k == IVE_KIND_CHEB && k1 == IVE_KIND_CHEB) VMF_IVE_BWD(IVE_KIND_CHEB, IVE_KIND_CHEB);
+  else if (k == IVE_KIND_HALF && k1 == IVE_KIND_HALF) VMF_IVE_BWD(IVE_KIND_HALF, IVE_KIND_HALF);
+  else if (k == IVE_KIND_GENERIC && k1 == IVE_KIND_CHEB) VMF_IVE_BWD(IVE_KIND_GENERIC, IVE_KIND_CHEB);
+  else if (k == IVE_KIND_GENERIC && k1 == IVE_KIND_GENERIC) VMF_IVE_BWD(IVE_KIND_GENERIC, IVE_KIND_GENERIC);
+  else if (k == IVE_KIND_GENERIC && k1 == IVE_KIND_HALF) VMF_IVE_BWD(IVE_KIND_GENERIC, IVE_KIND_HALF);
+  else VMF_IVE_BWD(IVE_KIND_SLOW, IVE_KIND_SLOW);
+#undef VMF_IVE_BWD
   return vmf_check_launch("vmf_ive_bwd");
 }
 

@@ -10,11 +10,13 @@ int vmf_check_launch(const char*) { return 0; }
 extern "C" {
 void hc_ive_fwd(double v, const double* z, double* out, int64_t n) {
   BesselOrder o = make_bessel_order(v, !(v == 0.0 || v == 1.0));
-  for (int64_t i = 0; i < n; ++i) out[i] = ive_eval(o, z[i]);
+  const IveTab tab = make_ive_tab(o);  // what vmf_ive_fwd hands its kernel
+  for (int64_t i = 0; i < n; ++i) out[i] = ive_eval_tab(o, tab, ive_kind_of(o), z[i]);
 }
 void hc_ive_vm1(double v, const double* z, double* out, int64_t n) {
   BesselOrder o = make_bessel_order(v - 1.0, v != 1.0);
-  for (int64_t i = 0; i < n; ++i) out[i] = ive_eval(o, z[i]);
+  const IveTab tab = make_ive_tab(o);  // what vmf_ive_bwd hands its kernel for the order v - 1
+  for (int64_t i = 0; i < n; ++i) out[i] = ive_eval_tab(o, tab, ive_kind_of(o), z[i]);
 }
 void hc_log_ive(double v, const double* z, double* out, int64_t n) {
   double lg = lgamma(v + 1.0);
