@@ -5,6 +5,7 @@
 #include <mutex>
 
 #include "vmf_math.h"
+#include "kl_m2_table.h"
 
 // ---- ive ---------------------------------------------------------------------------------------------
 // The reference moves z to the host, calls scipy (AMOS / cephes, double internally for either dtype) and
@@ -166,11 +167,69 @@ __device__ __forceinline__ double sum4_to_double(const T (&v)[4]) {
 // range check per four elements instead of the per-element region branches (spherical 27 -> 19 instructions per element);
 // a quad with any element outside the range -- or NaN -- takes the per-element form.  Both call the same functions
 // (the two inlined copies may differ in the last bit: the compiler contracts them separately).
+// `tab`: the block's LDS copy of the m = 2 table (fp32 instantiations of the two S^1 variants), null otherwise.
 template <typename T, bool BESSEL, int VARIANT>
-__device__ __forceinline__ void kl_eval_value4(const T (&k)[4], T (&o)[4], const KlBessel& kb) {
+__device__ __forceinline__ void kl_eval_value4(const T (&k)[4], T (&o)[4], const KlBessel& kb, const f32x4* tab) {
 #pragma unroll
   for (int x = 0; x < 4; ++x) o[x] = kl_eval_value<T, BESSEL>(k[x], VARIANT, kb);
 }
+
+// ---- the two S^1 variants in single precision: a piecewise cubic read from LDS -----------------------------------------
+// KL(vM(kappa) || U(S^1)) = kappa I1/I0 - log I0 through kl_m2_table.h: the float's exponent and top mantissa bits pick
+// the piece, the remaining mantissa bits are the position inside it; one 128-bit LDS read and three fused multiply-adds
+// per element, no transcendental, the same instructions for every concentration (the two-polynomial form of
+// kl_m2_value_f32 costs a wave of a mixed batch both chains, 12 + 17 terms, a logarithm and a reciprocal: 40 vector
+// instructions per element against 16).  VMF_KL_S1_I0I1 keeps the reference's overflow behaviour: NaN from 88.75 on,
+// the value-and-derivative form, which builds e^kappa and decides the overflow itself, in the window (88.70, 88.75).
+constexpr bool kl_uses_m2_table(int variant, int elem_size) {
+  return elem_size == 4 && (variant == VMF_KL_S1_I0I1 || variant == VMF_KL_STABLE_M2);
+}
+__device__ __forceinline__ void kl_m2_stage_table(f32x4* tab) {
+  for (int i = threadIdx.x; i < KLM2_T_N; i += blockDim.x) tab[i] = *reinterpret_cast<const f32x4*>(KLM2_T[i]);
+  __syncthreads();
+}
+// false: the element is outside the table (or in the S^1 form's overflow window): the caller takes kl_eval_value
+template <int VARIANT>
+__device__ __forceinline__ bool kl_m2_table_value(const f32x4* tab, float kappa, float* out) {
+  const float a = ::fabsf(kappa);
+  const uint32_t bits = __float_as_uint(a);
+  const uint32_t idx = (bits >> (23 - KLM2_T_SUB_BITS)) - ((127u + KLM2_T_E0) << KLM2_T_SUB_BITS);
+  bool ok = idx < (uint32_t)KLM2_T_N;  // also false for NaN / inf (their exponent is past the table)
+  if (VARIANT == VMF_KL_S1_I0I1) ok = ok && (a <= 88.70f || a >= 88.75f);
+  const f32x4 c = tab[ok ? idx : 0u];
+  const uint32_t tb = ((bits & ((1u << (23 - KLM2_T_SUB_BITS)) - 1u)) << KLM2_T_SUB_BITS) | 0x3F800000u;
+  const float t = __uint_as_float(tb) - 1.0f;
+  const float v = ::fmaf(::fmaf(::fmaf(c.w, t, c.z), t, c.y), t, c.x);
+  *out = (VARIANT == VMF_KL_S1_I0I1 && a >= 88.75f) ? NAN : v;  // e^a = inf: inf / inf in the reference
+  return ok;
+}
+// Elements the table does not cover.  ONE copy of this code per kernel, not one per unrolled position: in the S^1 form's
+// overflow window the value is a difference of two numbers near 88 (a few 1e-6 of rounding), and copies that the
+// compiler contracts differently would make an element's value depend on where in a block's trip it sits.
+template <int VARIANT>
+__device__ __attribute__((noinline)) float kl_m2_uncovered_f32(float k) {
+  const KlBessel none = {};  // the single-precision forms never touch the double-precision Bessel orders
+  return kl_eval_value<float, false>(k, VARIANT, none);
+}
+template <bool BESSEL, int VARIANT>
+__device__ __forceinline__ float kl_m2_value1(const f32x4* tab, float k, const KlBessel& kb) {
+  float v;
+  if (kl_m2_table_value<VARIANT>(tab, k, &v)) return v;
+  if (!BESSEL) return kl_m2_uncovered_f32<VARIANT>(k);
+  return kl_eval_value<float, BESSEL>(k, VARIANT, kb);
+}
+#define VMF_KL_QUAD_M2(BESSEL, V)                                                                              \
+  template <>                                                                                                  \
+  __device__ __forceinline__ void kl_eval_value4<float, BESSEL, V>(const float (&k)[4], float (&o)[4],         \
+                                                                   const KlBessel& kb, const f32x4* tab) {     \
+    bool ok = true;                                                                                            \
+    _Pragma("unroll") for (int x = 0; x < 4; ++x) ok = kl_m2_table_value<V>(tab, k[x], &o[x]) && ok;            \
+    if (ok) return;                                                                                            \
+    _Pragma("unroll") for (int x = 0; x < 4; ++x) o[x] = kl_m2_value1<BESSEL, V>(tab, k[x], kb);                \
+  }
+VMF_KL_QUAD_M2(false, VMF_KL_S1_I0I1)
+VMF_KL_QUAD_M2(false, VMF_KL_STABLE_M2)
+#undef VMF_KL_QUAD_M2
 template <int VARIANT>
 __device__ __forceinline__ bool kl_quad_m3(const float (&k)[4], float (&o)[4]) {
   constexpr float hi_limit = VARIANT == VMF_KL_SPHERICAL_PIECEWISE ? 1000.0f
@@ -202,7 +261,7 @@ __device__ __forceinline__ bool kl_quad_m3(const float (&k)[4], float (&o)[4]) {
 #define VMF_KL_QUAD_M3(BESSEL, V)                                                                              \
   template <>                                                                                                  \
   __device__ __forceinline__ void kl_eval_value4<float, BESSEL, V>(const float (&k)[4], float (&o)[4],         \
-                                                                   const KlBessel& kb) {                       \
+                                                                   const KlBessel& kb, const f32x4*) {         \
     if (kl_quad_m3<V>(k, o)) return;                                                                           \
     _Pragma("unroll") for (int x = 0; x < 4; ++x) o[x] = kl_eval_value<float, BESSEL>(k[x], V, kb);            \
   }
@@ -219,6 +278,10 @@ __global__ __launch_bounds__(KL_BLOCK) void kl_fwd_kernel(const T* __restrict__ 
   constexpr int variant = VARIANT;
   constexpr int KL_UNROLL = kl_unroll(VARIANT);
   __shared__ double red[KL_BLOCK / 64];
+  constexpr bool TABLE = kl_uses_m2_table(VARIANT, sizeof(T));
+  __shared__ f32x4 s_tab[TABLE ? KLM2_T_N : 1];
+  if (TABLE) kl_m2_stage_table(s_tab);
+  const f32x4* const tab = TABLE ? s_tab : nullptr;
   double acc = 0;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -238,14 +301,16 @@ __global__ __launch_bounds__(KL_BLOCK) void kl_fwd_kernel(const T* __restrict__ 
       const int64_t i = base + u * blockDim.x + threadIdx.x;
       if (i < nvec) {
         Vec4<T> o4;
-        kl_eval_value4<T, BESSEL, VARIANT>(k4[u].v, o4.v, kb);
+        kl_eval_value4<T, BESSEL, VARIANT>(k4[u].v, o4.v, kb, tab);
         if (out) *reinterpret_cast<Vec4<T>*>(out + 4 * i) = o4;
         acc += sum4_to_double(o4.v);
       }
     }
   }
   for (int64_t i = 4 * nvec + tid; i < n; i += stride) {
-    T kl = kl_eval_value<T, BESSEL>(kappa[i], variant, kb);
+    T kl;
+    if constexpr (TABLE) kl = kl_m2_value1<BESSEL, VARIANT>(tab, kappa[i], kb);
+    else kl = kl_eval_value<T, BESSEL>(kappa[i], variant, kb);
     if (out) out[i] = kl;
     acc += (double)kl;
   }
