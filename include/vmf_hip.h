@@ -176,7 +176,8 @@ int vmf_kl_fwd(const void* kappa, void* out, double* sum_out, double* workspace,
  * are refused (VMF_ERR_UNSUPPORTED).  Every call on one GPU shares that GPU's array: calls that may overlap there
  * (different streams) race on it -- order them, or give the overlapping ones vmf_kl_fwd with workspaces of their own.
  * Nothing in the array needs clearing between calls.  The first call on a device looks the array's address up
- * (hipGetSymbolAddress); make it before a capture begins. */
+ * (hipGetSymbolAddress); make it before a capture begins.  The array used is the CURRENT device's: `stream` must
+ * belong to the current device (a stream of another device is refused with VMF_ERR_BAD_ARG). */
 #define VMF_KL_STATIC_MAX_N ((int64_t)1 << 30)
 int vmf_kl_fwd_static(const void* kappa, void* out, double* sum_out, double alpha, int64_t n, int variant, int dtype,
                       vmf_stream_t stream);

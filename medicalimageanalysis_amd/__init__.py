@@ -44,14 +44,20 @@ def _parent_package(name):
     """The caller's own package of that name when one is importable (the reference's `model/` also holds train.py and
     infer.py, which are not replaced and must keep resolving), else an empty package that only carries the aliases."""
     pkg = sys.modules.get(name)
-    if pkg is not None and not getattr(pkg, "__name__", "").startswith("medicalimageanalysis_amd"):
-        return pkg
-    sys.modules.pop(name, None)
+    if pkg is not None and not getattr(pkg, "_vmf_alias_stub", False):
+        return pkg  # the caller's package, already imported: left exactly as it is (never popped, never re-executed)
+    if pkg is not None:
+        del sys.modules[name]  # an empty stub from an earlier install_aliases(): look again, the path may have changed
     try:
         pkg = importlib.import_module(name)
-    except ModuleNotFoundError:
+    except ModuleNotFoundError as e:
+        if e.name != name:
+            # the caller HAS such a package and its own __init__ failed on a missing dependency: that is the caller's
+            # error to see, not something to paper over with an empty package
+            raise
         pkg = types.ModuleType(name, "alias package created by medicalimageanalysis_amd.install_aliases()")
         pkg.__path__ = []
+        pkg._vmf_alias_stub = True
         sys.modules[name] = pkg
     return pkg
 

@@ -149,19 +149,26 @@ def on_device(dev):
 
 
 _workspaces = {}
+_retired_workspaces = []
 
 
 def workspace(dev, n_doubles):
-    """Scratch of `n_doubles` float64 for a reduction's block partials, one per (device, stream, size), kept for the
-    life of the process: launches on one stream are ordered, so back-to-back calls may share it, and a train step
-    captured into a HIP graph then contains no allocation for it (the warm-up steps before the capture created it).
-    A first call made while the stream is capturing gets a buffer of its own from the capture's pool instead."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, n_doubles)
+    """Scratch of AT LEAST `n_doubles` float64 for a reduction's block partials (callers pass its real size on): ONE
+    buffer per (device, stream), grown in powers of two to the largest request seen, kept for the life of the process.
+    Launches on one stream are ordered, so back-to-back calls may share it, and a train step captured into a HIP graph
+    contains no allocation for it (the warm-up steps before the capture created it).  A buffer that is outgrown is kept
+    alive as well -- a graph captured earlier may still point at it -- which at most doubles the footprint of the
+    largest request.  A first call made while the stream is capturing gets a buffer of its own from the capture's pool."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
     ws = _workspaces.get(key)
-    if ws is None:
-        ws = torch.empty(n_doubles, device=dev, dtype=torch.float64)
-        if not torch.cuda.is_current_stream_capturing():
-            _workspaces[key] = ws
+    if ws is None or ws.numel() < n_doubles:
+        size = 1 << max(10, int(n_doubles - 1).bit_length())
+        new = torch.empty(size, device=dev, dtype=torch.float64)
+        if torch.cuda.is_current_stream_capturing():
+            return new
+        if ws is not None:
+            _retired_workspaces.append(ws)
+        _workspaces[key] = ws = new
     return ws
 
 

@@ -456,6 +456,17 @@ extern "C" int vmf_kl_fwd_static(const void* kappa, void* out, double* sum_out, 
               (long long)n, (long long)VMF_KL_STATIC_MAX_N);
   double* scratch = nullptr;
   if (sum_out) {
+    // the array is looked up for the CURRENT device: a stream that belongs to another GPU would launch there with this
+    // GPU's address
+    if (stream) {
+      hipDevice_t sdev = -1;
+      int cur = -1;
+      if (hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess && hipGetDevice(&cur) == hipSuccess)
+        VMF_REQUIRE((int)sdev == cur, VMF_ERR_BAD_ARG,
+                    "vmf_kl_fwd_static: the stream belongs to device %d, the current device is %d", (int)sdev, cur);
+      else
+        (void)hipGetLastError();  // a runtime without the query: nothing to compare
+    }
     int rc = kl_static_scratch(&scratch);
     if (rc) return rc;
   }

@@ -82,6 +82,20 @@ def elbo_loss(x, x_hat, kappa, gamma=1.0, beta=1.0, variant="spherical", reducti
     return _Elbo.apply(x, x_hat, kappa, a_rec, a_kl, VARIANTS[variant])
 
 
+def model_elbo(model, owner, x, x_hat, kappa, variant):
+    """`_elbo` of the VAE classes: gamma * mean((x - x_hat)^2) + beta * mean(model.kl_vmf_spherical_uniform(kappa))
+    (model/spherical_vae.py:132-138).  While the KL method is the one `owner` (the class of this package) defines, both
+    terms are one fused reduction with that method's formula; a subclass that overrides the method gets exactly the
+    reference's composition -- its own KL, `.mean()`, and the squared error over the broadcast shape -- so the override
+    is honoured as it would be in the reference."""
+    gamma, beta = model.config["gamma"], model.config["beta"]
+    if type(model).kl_vmf_spherical_uniform is owner.kl_vmf_spherical_uniform:
+        return elbo_loss(x, x_hat, kappa, gamma, beta, variant)
+    kl = model.kl_vmf_spherical_uniform(kappa).mean()
+    recon = torch.mean((x - x_hat) ** 2)
+    return gamma * recon + beta * kl
+
+
 class _BuildTorus(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z_theta, z_phi, R, r):

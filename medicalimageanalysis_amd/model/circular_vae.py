@@ -56,7 +56,7 @@ class CircularVAE(nn.Module):
     def _elbo(self, x, x_recon, posterior_params):
         z_mu, z_kappa = posterior_params
         q_z = VonMisesFisher3D(z_mu, z_kappa)
-        return _losses.elbo_loss(x, x_recon, q_z.scale, self.config["gamma"], self.config["beta"], "circular")  # :106-116
+        return _losses.model_elbo(self, CircularVAE, x, x_recon, q_z.scale, "circular")
 
     def kl_vmf_spherical_uniform(self, kappa) -> torch.Tensor:
         return _kl.kl_per_sample(kappa, "circular")  # :118-130

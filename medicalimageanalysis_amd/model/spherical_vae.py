@@ -83,7 +83,7 @@ class SphericalVAE(nn.Module):
         z_mu, z_kappa = posteriori_params
         q_z = VonMisesFisher3D(z_mu, z_kappa)
         p_z = SphericalUniform(dim=self.latent_dim - 1, device=x.device)  # noqa: F841  (built, unused: :130)
-        return _losses.elbo_loss(x, x_mu, q_z.scale, self.config["gamma"], self.config["beta"], "spherical")
+        return _losses.model_elbo(self, SphericalVAE, x, x_mu, q_z.scale, "spherical")
 
     def kl_vmf_spherical_uniform(self, kappa) -> torch.Tensor:
         """KL(vMF(mu, kappa) || Uniform(S^2)) per element, piecewise as model/spherical_vae.py:141-184."""

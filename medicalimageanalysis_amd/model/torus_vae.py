@@ -90,7 +90,7 @@ class ToroidalVAE(nn.Module):
         z_mu, z_kappa = posteriori_params
         q_z = VonMisesFisher3D(z_mu, z_kappa)
         p_z = SphericalUniform(dim=self.latent_dim - 1, device=x.device)  # noqa: F841
-        return _losses.elbo_loss(x, x_mu, q_z.scale, self.config["gamma"], self.config["beta"], "torus")
+        return _losses.model_elbo(self, ToroidalVAE, x, x_mu, q_z.scale, "torus")
 
     def kl_vmf_spherical_uniform(self, kappa) -> torch.Tensor:
         """unguarded form of model/torus_vae.py:182-194 (NaN once sinh overflows, like the reference)"""

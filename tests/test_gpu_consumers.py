@@ -96,6 +96,30 @@ def test_elbo_broadcast_shapes_vs_torch_autograd(shape_x, shape_h, tag):
         np.testing.assert_allclose(a, N(t.grad), rtol=TOL[tag]["rtol"], atol=10 * TOL[tag]["atol"])
 
 
+def test_elbo_honours_a_subclass_that_overrides_the_kl_method():
+    """model/spherical_vae.py:132-134 calls self.kl_vmf_spherical_uniform: a subclass with its own KL must see it used
+    (the fused reduction serves the stock method only), and the stock class must give the reference's composition"""
+    from medicalimageanalysis_amd.model.spherical_vae import SphericalVAE
+    cfg = dict(extrinsic_dim=12, latent_dim=3, sftbeta=1.0, encoder_width=16, encoder_depth=1, decoder_width=16,
+               decoder_depth=1, dropout_p=0.0, device="cuda", gamma=0.7, beta=0.3)
+
+    class Mine(SphericalVAE):
+        def kl_vmf_spherical_uniform(self, kappa):
+            return 2.0 * kappa   # anything recognisable
+
+    torch.manual_seed(0)
+    x = torch.rand(8, 12, device=DEV)
+    x_mu = torch.rand(8, 8, 12, device=DEV)
+    z_mu = torch.randn(8, 3, device=DEV)
+    kap = torch.rand(8, 1, device=DEV) * 30 + 1
+    stock, mine = SphericalVAE(cfg), Mine(cfg)
+    rec = torch.mean((x - x_mu) ** 2)
+    got = mine._elbo(x, x_mu, (z_mu, kap))
+    np.testing.assert_allclose(N(got), N(0.7 * rec + 0.3 * (2.0 * kap).mean()), rtol=1e-6)
+    got = stock._elbo(x, x_mu, (z_mu, kap))
+    np.testing.assert_allclose(N(got), N(0.7 * rec + 0.3 * stock.kl_vmf_spherical_uniform(kap).mean()), rtol=1e-5)
+
+
 def test_elbo_sum_reduction_is_the_s1_loss():
     """regular_cnn/s1_vae.py:70-92: mse_sum + sum_i (k I1/I0 - log I0)"""
     from medicalimageanalysis_amd.model.s1_vae import loss_function

@@ -66,6 +66,21 @@ def record_margin(name, err, tol):
     return used
 
 
+GRAD_RT32 = 5e-4  # fp32 gradients: relative to the element plus the same fraction of the tensor's largest element
+
+
+def close_grad(got, ref, tag, name, rt64=1e-9):
+    """gradient tensors: |got - ref| <= rt (|ref| + max |ref|), rt = 5e-4 in fp32 (the randomised sweeps measure 6e-5);
+    the largest error and the share of the allowance it used are recorded like the draws' (MARGINS)"""
+    got64, ref64 = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    rt = rt64 if tag == "f64" else GRAD_RT32
+    tol = rt * (np.abs(ref64) + np.abs(ref64).max())
+    err = np.abs(got64 - ref64)
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0].split("[")[0]
+    used = record_margin(f"{test}_{name}_{tag}", err, np.maximum(tol, 1e-300))
+    assert (err <= tol).all(), (name, tag, float(err.max()), used)
+
+
 def close_vmf3(z, z_ref, tag, loc, scale, u, eps, ss=(), name="vmf3"):
     """fp64: |dz| <= 1e-9.  fp32: what the rounding of w itself allows, plus 2e-6 for the rest of the row: the reference
     forms w = 1 + L/kappa in fp32 with L = logsumexp(log u, log(1-u) - 2 kappa), so an error of a few ulp in L
@@ -170,9 +185,8 @@ def test_vmf3_backward_fp32_vs_oracle(oracle, outer):
     tl, tk = T(loc).requires_grad_(), T(scale).requires_grad_()
     z = VonMisesFisher3D(tl, tk, validate_args=False).rsample_with_noise(T(u), T(eps))
     (z * T(c)).sum().backward()
-    sc_l, sc_k = np.abs(dl_ref).max(), np.abs(dk_ref).max()
-    np.testing.assert_allclose(N(tl.grad), dl_ref, rtol=2e-3, atol=2e-3 * sc_l)
-    np.testing.assert_allclose(N(tk.grad), dk_ref, rtol=2e-3, atol=2e-3 * sc_k)
+    close_grad(N(tl.grad), dl_ref, "f32", "dloc")
+    close_grad(N(tk.grad), dk_ref, "f32", "dscale")
 
 
 @pytest.mark.parametrize("tag", ["f64", "f32"])
@@ -215,8 +229,8 @@ def test_vmf3_softplus_fold_matches_torch_softplus(monkeypatch, tag, shape):
     else:
         np.testing.assert_allclose(N(kap), N(kap_ref), rtol=2e-6)
         np.testing.assert_allclose(N(z), N(z_ref), rtol=0, atol=2e-5)   # kappa moves by an ulp, w by |L| / kappa of it
-        np.testing.assert_allclose(N(la.grad), N(lb.grad), rtol=2e-3, atol=2e-3 * float(lb.grad.abs().max()))
-        np.testing.assert_allclose(N(ra.grad), N(rb.grad), rtol=2e-3, atol=2e-3 * float(rb.grad.abs().max()))
+        close_grad(N(la.grad), N(lb.grad), "f32", "dloc")
+        close_grad(N(ra.grad), N(rb.grad), "f32", "draw")
 
 
 @pytest.mark.parametrize("tag", ["f64", "f32"])
@@ -239,9 +253,8 @@ def test_vmf3_outer_product_shapes_vs_oracle(oracle, tag, ni, nj):
     assert z.shape == (ni, nj, 3)
     close_vmf3(N(z), z_ref, tag, loc, scale, u, eps, name="vmf3_outer")
     (z * T(c)).sum().backward()
-    rt = 1e-9 if tag == "f64" else 2e-3
-    np.testing.assert_allclose(N(tl.grad), dl_ref, rtol=rt, atol=rt * np.abs(dl_ref).max())
-    np.testing.assert_allclose(N(tk.grad), dk_ref, rtol=rt, atol=rt * np.abs(dk_ref).max())
+    close_grad(N(tl.grad), dl_ref, tag, "dloc")
+    close_grad(N(tk.grad), dk_ref, tag, "dscale")
     # same bits on a second run (fixed summation order, no atomics)
     g1, g2 = tl.grad.clone(), tk.grad.clone()
     tl.grad = tk.grad = None

@@ -80,3 +80,45 @@ def test_static_scratch_kl_edge_cases():
     torch.cuda.synchronize(DEV)
     np.testing.assert_allclose(out.cpu().numpy(), np.log(1.0) - np.log(np.sinh(1.0)) + 1.0 / np.tanh(1.0) - 1.0,
                                rtol=1e-5)
+
+
+def test_static_scratch_kl_allocates_nothing_and_replays_under_graph_capture():
+    """what the entry point is for: after one warm call (which resolves the array's address) the call allocates no
+    device memory -- neither through torch's allocator nor behind it -- and can be captured into a HIP graph on a side
+    stream; replays on changed concentrations give the bits of vmf_kl_fwd"""
+    lib = _lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(9)
+    n = (1 << 20) + 5
+    kappa = torch.exp(torch.rand(n, device=DEV, generator=g) * np.log(50.0))
+    out = torch.empty_like(kappa)
+    acc = torch.zeros(1, device=DEV, dtype=torch.float64)
+    variant = _lib.KL_STABLE_M2
+
+    def call(stream):
+        rc = lib.vmf_kl_fwd_static(_lib.ptr(kappa), _lib.ptr(out), _lib.ptr(acc), 1.0 / n, n, variant, _lib.VMF_F32,
+                                   C.c_void_p(stream.cuda_stream))
+        assert rc == 0, lib.vmf_last_error_string()
+
+    call(torch.cuda.current_stream(DEV))   # warm call: the address look-up happens here
+    torch.cuda.synchronize(DEV)
+    free0, _ = torch.cuda.mem_get_info(DEV)
+    alloc0, reserved0 = torch.cuda.memory_allocated(DEV), torch.cuda.memory_reserved(DEV)
+    for _ in range(3):
+        call(torch.cuda.current_stream(DEV))
+    torch.cuda.synchronize(DEV)
+    free1, _ = torch.cuda.mem_get_info(DEV)
+    assert torch.cuda.memory_allocated(DEV) == alloc0 and torch.cuda.memory_reserved(DEV) == reserved0
+    assert free1 == free0, (free0, free1)
+    side = torch.cuda.Stream(DEV)
+    graph = torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream(DEV))
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            call(side)
+    for scale in (0.5, 1.7):
+        kappa.mul_(scale)
+        graph.replay()
+        torch.cuda.synchronize(DEV)
+        got_sum, got_out = acc.cpu().numpy().copy(), out.cpu().numpy().copy()
+        (s_ws, o_ws), _ = _both(kappa, variant, True)
+        assert got_sum.tobytes() == s_ws.tobytes() and got_out.tobytes() == o_ws.tobytes()

@@ -117,8 +117,10 @@ def main():
         for mode in ("philox", "torch"):
             os.environ["VMF_RNG"] = mode
             ms = timeit(lambda: q.rsample())
+            # the (B, B, 3) result is written once (12 B per output row); loc, scale -- and u, eps with torch noise -- are
+            # O(B) inputs
             row(f"VonMisesFisher3D.rsample B={B} scale (B,1) -> ({B},{B},3), {mode} noise (incl. python)", ms,
-                B * B * (12 if mode == "philox" else 28), B * B, "rows")
+                B * B * 12 + B * (16 if mode == "philox" else 32), B * B, "rows")
         if B == 4096:
             zq = q.rsample().detach().requires_grad_(False)
             lq = loc.clone().requires_grad_()
@@ -129,7 +131,9 @@ def main():
                 lq.grad = kq.grad = None
                 VonMisesFisher3D(lq, kq, validate_args=False).rsample().backward(gzq)
             ms = timeit(fbq)
-            row(f"  forward + backward of the same (B={B})", ms, B * B * (12 + 28 + 12 + 16), B * B, "rows")
+            # forward writes z, backward reads grad z: 12 B per output row each; operands, gradients and the backward's
+            # partial sums are O(B) and O(B * B / tile height)
+            row(f"  forward + backward of the same (B={B})", ms, B * B * (12 + 12) + B * 64, B * B, "rows")
             del zq, gzq
     os.environ["VMF_RNG"] = "torch"
 
