@@ -6,6 +6,7 @@
 
 #include "vmf_math.h"
 #include "kl_m2_table.h"
+#include "kl_m3_table.h"
 
 // ---- ive ---------------------------------------------------------------------------------------------
 // The reference moves z to the host, calls scipy (AMOS / cephes, double internally for either dtype) and
@@ -184,8 +185,18 @@ __device__ __forceinline__ void kl_eval_value4(const T (&k)[4], T (&o)[4], const
 constexpr bool kl_uses_m2_table(int variant, int elem_size) {
   return elem_size == 4 && (variant == VMF_KL_S1_I0I1 || variant == VMF_KL_STABLE_M2);
 }
-__device__ __forceinline__ void kl_m2_stage_table(f32x4* tab) {
-  for (int i = threadIdx.x; i < KLM2_T_N; i += blockDim.x) tab[i] = *reinterpret_cast<const f32x4*>(KLM2_T[i]);
+// the m = 3 variants read their table in the 128-bit instantiation only (its four-element fast path)
+constexpr bool kl_uses_m3_table(int variant, int elem_size, int vec) { return elem_size == 4 && vec == 4 && !kl_uses_m2_table(variant, 4); }
+constexpr int kl_table_size(int variant, int elem_size, int vec) {
+  return kl_uses_m2_table(variant, elem_size) ? KLM2_T_N : (kl_uses_m3_table(variant, elem_size, vec) ? KLM3_T_N : 1);
+}
+template <int VARIANT>
+__device__ __forceinline__ void kl_stage_table(f32x4* tab) {
+  const float(*src)[4] = (VARIANT == VMF_KL_S1_I0I1 || VARIANT == VMF_KL_STABLE_M2) ? KLM2_T
+                         : (VARIANT == VMF_KL_SPHERICAL_PIECEWISE ? KLM3_T_EPS1E8
+                            : (VARIANT == VMF_KL_CIRCULAR_EPS ? KLM3_T_EPS1E6 : KLM3_T_EPS0));
+  const int n = (VARIANT == VMF_KL_S1_I0I1 || VARIANT == VMF_KL_STABLE_M2) ? KLM2_T_N : KLM3_T_N;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) tab[i] = *reinterpret_cast<const f32x4*>(src[i]);
   __syncthreads();
 }
 // false: the element is outside the table (or in the S^1 form's overflow window): the caller takes kl_eval_value
@@ -203,11 +214,13 @@ __device__ __forceinline__ bool kl_m2_table_value(const f32x4* tab, float kappa,
   *out = (VARIANT == VMF_KL_S1_I0I1 && a >= 88.75f) ? NAN : v;  // e^a = inf: inf / inf in the reference
   return ok;
 }
-// Elements the table does not cover.  ONE copy of this code per kernel, not one per unrolled position: in the S^1 form's
-// overflow window the value is a difference of two numbers near 88 (a few 1e-6 of rounding), and copies that the
-// compiler contracts differently would make an element's value depend on where in a block's trip it sits.
+// Elements the tables do not cover (concentrations below 1, the windows around the reference's overflow points, NaN,
+// values past the tables' end).  ONE copy of this code per kernel, not one per unrolled position: it keeps the
+// streaming loop small, and in the S^1 form's overflow window the value is a difference of two numbers near 88 (a few
+// 1e-6 of rounding) -- copies that the compiler contracts differently would make an element's value depend on where in
+// a block's trip it sits.
 template <int VARIANT>
-__device__ __attribute__((noinline)) float kl_m2_uncovered_f32(float k) {
+__device__ __attribute__((noinline)) float kl_uncovered_f32(float k) {
   const KlBessel none = {};  // the single-precision forms never touch the double-precision Bessel orders
   return kl_eval_value<float, false>(k, VARIANT, none);
 }
@@ -215,7 +228,7 @@ template <bool BESSEL, int VARIANT>
 __device__ __forceinline__ float kl_m2_value1(const f32x4* tab, float k, const KlBessel& kb) {
   float v;
   if (kl_m2_table_value<VARIANT>(tab, k, &v)) return v;
-  if (!BESSEL) return kl_m2_uncovered_f32<VARIANT>(k);
+  if (!BESSEL) return kl_uncovered_f32<VARIANT>(k);
   return kl_eval_value<float, BESSEL>(k, VARIANT, kb);
 }
 #define VMF_KL_QUAD_M2(BESSEL, V)                                                                              \
@@ -230,11 +243,21 @@ __device__ __forceinline__ float kl_m2_value1(const f32x4* tab, float k, const K
 VMF_KL_QUAD_M2(false, VMF_KL_S1_I0I1)
 VMF_KL_QUAD_M2(false, VMF_KL_STABLE_M2)
 #undef VMF_KL_QUAD_M2
+// one table element: c0 + t (c1 + t (c2 + t c3)) of the piece that k's exponent and top mantissa bits select; k must
+// lie inside the table (1 <= k < 2^28: the callers' range checks see to it)
+__device__ __forceinline__ float kl_m3_table_lookup(const f32x4* tab, float k) {
+  const uint32_t bits = __float_as_uint(k);
+  const uint32_t idx = (bits >> (23 - KLM3_T_SUB_BITS)) - ((127u + KLM3_T_E0) << KLM3_T_SUB_BITS);
+  const f32x4 c = tab[idx < (uint32_t)KLM3_T_N ? idx : 0u];
+  const uint32_t tb = ((bits & ((1u << (23 - KLM3_T_SUB_BITS)) - 1u)) << KLM3_T_SUB_BITS) | 0x3F800000u;
+  const float t = __uint_as_float(tb) - 1.0f;
+  return ::fmaf(::fmaf(::fmaf(c.w, t, c.z), t, c.y), t, c.x);
+}
 template <int VARIANT>
-__device__ __forceinline__ bool kl_quad_m3(const float (&k)[4], float (&o)[4]) {
+__device__ __forceinline__ bool kl_quad_m3(const float (&k)[4], float (&o)[4], const f32x4* tab) {
+  // (the table ends at 2^28: beyond, the overflow-free form's log k + ln 2 - 1 is left to the per-element path)
   constexpr float hi_limit = VARIANT == VMF_KL_SPHERICAL_PIECEWISE ? 1000.0f
-                             : (VARIANT == VMF_KL_STABLE_M3 ? 3.0e38f : KL_M3_UNIFIED_MAX);
-  constexpr float eps = VARIANT == VMF_KL_SPHERICAL_PIECEWISE ? 1e-8f : (VARIANT == VMF_KL_CIRCULAR_EPS ? 1e-6f : 0.0f);
+                             : (VARIANT == VMF_KL_STABLE_M3 ? 2.6e8f : KL_M3_UNIFIED_MAX);
   const float lo = fminf(fminf(k[0], k[1]), fminf(k[2], k[3])), hi = fmaxf(fmaxf(k[0], k[1]), fmaxf(k[2], k[3]));
   // fminf / fmaxf drop a NaN operand: the sum test catches it
   const bool in_range = lo >= 1.0f && hi <= hi_limit && (k[0] + k[1] + k[2] + k[3]) == (k[0] + k[1] + k[2] + k[3]);
@@ -250,20 +273,19 @@ __device__ __forceinline__ bool kl_quad_m3(const float (&k)[4], float (&o)[4]) {
     for (int x = 0; x < 4; ++x) ok = ok && k[x] >= 1.0f && (k[x] <= KL_M3_UNIFIED_MAX || k[x] >= KL_M3_NAN_MIN);
     if (!ok) return false;  // (a NaN fails k >= 1)
 #pragma unroll
-    for (int x = 0; x < 4; ++x) o[x] = k[x] >= KL_M3_NAN_MIN ? NAN : kl_m3_unified_value(k[x], eps);
+    for (int x = 0; x < 4; ++x) o[x] = k[x] >= KL_M3_NAN_MIN ? NAN : kl_m3_table_lookup(tab, k[x]);
     return true;
   }
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
-    o[x] = VARIANT == VMF_KL_STABLE_M3 ? kl_m3_stable_value(k[x]) : kl_m3_unified_value(k[x], eps);
+  for (int x = 0; x < 4; ++x) o[x] = kl_m3_table_lookup(tab, k[x]);
   return true;
 }
 #define VMF_KL_QUAD_M3(BESSEL, V)                                                                              \
   template <>                                                                                                  \
   __device__ __forceinline__ void kl_eval_value4<float, BESSEL, V>(const float (&k)[4], float (&o)[4],         \
-                                                                   const KlBessel& kb, const f32x4*) {         \
-    if (kl_quad_m3<V>(k, o)) return;                                                                           \
-    _Pragma("unroll") for (int x = 0; x < 4; ++x) o[x] = kl_eval_value<float, BESSEL>(k[x], V, kb);            \
+                                                                   const KlBessel& kb, const f32x4* tab) {     \
+    if (kl_quad_m3<V>(k, o, tab)) return;                                                                           \
+    _Pragma("unroll") for (int x = 0; x < 4; ++x) o[x] = kl_uncovered_f32<V>(k[x]);                            \
   }
 VMF_KL_QUAD_M3(false, VMF_KL_SPHERICAL_PIECEWISE)
 VMF_KL_QUAD_M3(false, VMF_KL_TORUS_RAW)
@@ -278,10 +300,11 @@ __global__ __launch_bounds__(KL_BLOCK) void kl_fwd_kernel(const T* __restrict__ 
   constexpr int variant = VARIANT;
   constexpr int KL_UNROLL = kl_unroll(VARIANT);
   __shared__ double red[KL_BLOCK / 64];
-  constexpr bool TABLE = kl_uses_m2_table(VARIANT, sizeof(T));
-  __shared__ f32x4 s_tab[TABLE ? KLM2_T_N : 1];
-  if (TABLE) kl_m2_stage_table(s_tab);
-  const f32x4* const tab = TABLE ? s_tab : nullptr;
+  constexpr bool TABLE = kl_uses_m2_table(VARIANT, sizeof(T));              // every fp32 element goes through it
+  constexpr bool TABLE3 = kl_uses_m3_table(VARIANT, sizeof(T), VEC);        // the four-element fast path does
+  __shared__ f32x4 s_tab[kl_table_size(VARIANT, sizeof(T), VEC)];
+  if (TABLE || TABLE3) kl_stage_table<VARIANT>(s_tab);
+  const f32x4* const tab = (TABLE || TABLE3) ? s_tab : nullptr;
   double acc = 0;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;

@@ -61,6 +61,10 @@ class GraphedTrainStep:
         optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
             self.static_loss = self._eager_step(zero=False)
+        if tuner is not None:
+            # the captured launches keep the kernels chosen during the warm-up; the process-wide switch goes back to what
+            # the caller had, so that code outside this step is not silently routed through TunableOp
+            tuner.enable(was[0])
 
     def _eager_step(self, zero=True):
         if zero:

@@ -66,11 +66,11 @@ def record_margin(name, err, tol):
     return used
 
 
-GRAD_RT32 = 5e-4  # fp32 gradients: relative to the element plus the same fraction of the tensor's largest element
+GRAD_RT32 = 1e-4  # fp32 gradients: relative to the element plus the same fraction of the tensor's largest element
 
 
 def close_grad(got, ref, tag, name, rt64=1e-9):
-    """gradient tensors: |got - ref| <= rt (|ref| + max |ref|), rt = 5e-4 in fp32 (the randomised sweeps measure 6e-5);
+    """gradient tensors: |got - ref| <= rt (|ref| + max |ref|), rt = 1e-4 in fp32 (measured: 3e-6 of it, see the recorded margins);
     the largest error and the share of the allowance it used are recorded like the draws' (MARGINS)"""
     got64, ref64 = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
     rt = rt64 if tag == "f64" else GRAD_RT32
@@ -1876,7 +1876,7 @@ def test_graphed_general_m_step_under_default_torch_rng(monkeypatch):
 
 def test_graphed_step_with_fused_adam_and_tuned_gemms(tmp_path, monkeypatch):
     """GraphedTrainStep(tune_gemms=True): PyTorch's TunableOp picks the nn.Linear kernels during the warm-up steps, the
-    capture uses them, tuning is switched off again afterwards and nothing is written into the working directory"""
+    capture uses them, TunableOp's switches are restored afterwards and nothing is written into the working directory"""
     from medicalimageanalysis_amd.graph import GraphedTrainStep
     from medicalimageanalysis_amd.model.hyperspherical_vae import HypersphericalVAE
     monkeypatch.chdir(tmp_path)
@@ -1896,7 +1896,8 @@ def test_graphed_step_with_fused_adam_and_tuned_gemms(tmp_path, monkeypatch):
         model = HypersphericalVAE(cfg)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True, fused=True)
         step = GraphedTrainStep(model, opt, loss_fn, [x], warmup=2, tune_gemms=True)
-        assert tuner.is_enabled() and tuner.tuning_is_enabled() == before[1]
+        # both process-wide switches are back where the caller had them; the graph keeps the kernels it captured
+        assert tuner.is_enabled() == before[0] and tuner.tuning_is_enabled() == before[1]
         assert len(tuner.get_results()) > 0  # shapes were tuned
         losses = [float(step(x)) for _ in range(30)]
     finally:
