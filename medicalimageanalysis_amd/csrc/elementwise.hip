@@ -579,6 +579,16 @@ extern "C" int vmf_sphere_uniform_sample(const void* gauss, void* out, int64_t n
   return vmf_check_launch("vmf_sphere_uniform_sample");
 }
 
+// Counter noise of the S^1 sampler at dim = 2 (the circle): a row needs two normals = one Box-Muller pair = two words, so
+// ONE Philox call serves the rows 2p and 2p+1: Philox(index p = row >> 1, slot 0x30000), words (x, y) for the even row,
+// (z, w) for the odd one.  (Wider rows keep one call per four elements: slot 0x30000 + chunk, index = row.)
+template <typename T>
+__device__ __forceinline__ void s1_circle_normals(uint64_t row, PhiloxKey key, T* n0, T* n1) {
+  const U4 r = philox4x32_10(row >> 1, 0x30000u, key);
+  const bool odd = (row & 1u) != 0u;
+  box_muller<T>(u01<T>(odd ? r.z : r.x), u01<T>(odd ? r.w : r.y), n0, n1);
+}
+
 // regular_cnn/s1_vae.py:48-55: z = F.normalize(mean*kappa + noise)  (eps 1e-12)
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void s1_projnormal_kernel(const T* __restrict__ mean, const T* __restrict__ kappa,
@@ -591,6 +601,10 @@ __global__ __launch_bounds__(256) void s1_projnormal_kernel(const T* __restrict_
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     T cache[4];
     int cc = -1;
+    if (dim == 2 && !noise) {  // the circle's noise layout: see s1_circle_normals
+      s1_circle_normals<T>(row0 + (uint64_t)i, key, &cache[0], &cache[1]);
+      cc = 0;
+    }
     T k = kappa[i], ss = 0, yg = 0;
     for (int c = 0; c < dim; ++c) {
       T y = mean[i * dim + c] * k + row_normal<T>(noise, i, dim, c, row0 + (uint64_t)i, 0x30000u, key, cache, &cc);
@@ -600,7 +614,7 @@ __global__ __launch_bounds__(256) void s1_projnormal_kernel(const T* __restrict_
     T nn = M<T>::sqrt(ss);
     bool clamped = nn < (T)1e-12;
     if (clamped) nn = (T)1e-12;
-    cc = -1;
+    if (!(dim == 2 && !noise)) cc = -1;  // (the circle's pair of normals is still in the cache)
     T dk = 0;
     for (int c = 0; c < dim; ++c) {
       T y = mean[i * dim + c] * k + row_normal<T>(noise, i, dim, c, row0 + (uint64_t)i, 0x30000u, key, cache, &cc);
@@ -616,8 +630,56 @@ __global__ __launch_bounds__(256) void s1_projnormal_kernel(const T* __restrict_
   }
 }
 
-// dim == 2 (the circle, the only shape the reference's S^1 VAE uses): one 64-bit access per operand row, one Philox
-// call and one Box-Muller pair per row, everything else in registers.  Same arithmetic as the general kernel above.
+// dim == 2 (the circle, the only shape the reference's S^1 VAE uses): a thread owns the GLOBAL pair of rows 2p, 2p+1 --
+// one 128-bit access per operand for both rows (aligned to the row, 8 bytes in fp32, which is all a global access needs
+// here) and ONE Philox call for both rows' Box-Muller pairs.  A call whose
+// first or last row has no partner in the call (odd row offset, odd count) handles that row alone with 64-bit accesses.
+// Same arithmetic as the general kernel above.
+template <typename T>
+struct RowPair {  // two rows of two values
+  T v[4];
+};
+// streaming (non-temporal) access to two rows at once, aligned to one row only
+template <typename T>
+__device__ __forceinline__ RowPair<T> load_rows2_nt(const T* base, int64_t row) {
+  typedef T V4 __attribute__((ext_vector_type(4), aligned(2 * sizeof(T))));
+  const V4 v = __builtin_nontemporal_load(reinterpret_cast<const V4*>(base + 2 * row));
+  RowPair<T> r;
+  r.v[0] = v.x; r.v[1] = v.y; r.v[2] = v.z; r.v[3] = v.w;
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void store_rows2_nt(T* base, int64_t row, const RowPair<T>& r) {
+  typedef T V4 __attribute__((ext_vector_type(4), aligned(2 * sizeof(T))));
+  const V4 v = {r.v[0], r.v[1], r.v[2], r.v[3]};
+  __builtin_nontemporal_store(v, reinterpret_cast<V4*>(base + 2 * row));
+}
+template <typename T, bool BWD>
+__device__ __forceinline__ void s1_circle_row(T m0, T m1, T k, T n0, T n1, T g0, T g1, T* o0, T* o1, T* dk) {
+  const T y0 = m0 * k + n0, y1 = m1 * k + n1;
+  T ss = 0;
+  ss += y0 * y0;
+  ss += y1 * y1;
+  // 1 / max(|y|, 1e-12): the 1-ulp hardware reciprocal square root for fp32, the library for fp64
+  const T nn = F<T>::sqrt(ss);
+  const bool clamped = nn < (T)1e-12;
+  const T rn = clamped ? (T)1e12 : F<T>::rsqrt(ss);
+  if (!BWD) {
+    *o0 = y0 * rn; *o1 = y1 * rn;
+  } else {
+    T yg = 0;
+    yg += y0 * g0;
+    yg += y1 * g1;
+    const T t = clamped ? (T)0 : yg * (rn * rn * rn);
+    const T dy0 = g0 * rn - y0 * t;
+    const T dy1 = g1 * rn - y1 * t;
+    *o0 = k * dy0; *o1 = k * dy1;
+    T d = 0;
+    d += m0 * dy0;
+    d += m1 * dy1;
+    *dk = d;
+  }
+}
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void s1_projnormal2_kernel(const T* __restrict__ mean, const T* __restrict__ kappa,
                                                              const T* __restrict__ noise, const T* __restrict__ gz,
@@ -625,42 +687,54 @@ __global__ __launch_bounds__(256) void s1_projnormal2_kernel(const T* __restrict
                                                              T* __restrict__ dkappa, int64_t n, uint64_t row0,
                                                              PhiloxArg ka) {
   const PhiloxKey key = philox_resolve(ka);
+  const uint64_t p0 = row0 >> 1;
+  const int64_t npairs = (int64_t)(((row0 + (uint64_t)n + 1u) >> 1) - p0);  // global pairs the call touches
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    // every array is touched once: non-temporal accesses
-    const Pair<T> mu = load_pair_nt<T>(mean, i);
-    const T k = __builtin_nontemporal_load(kappa + i);
-    T n0, n1;
-    if (noise) {
-      const Pair<T> e = load_pair_nt<T>(noise, i);
-      n0 = e.a; n1 = e.b;
-    } else {
-      const U4 r = philox4x32_10(row0 + (uint64_t)i, 0x30000u, key);
-      box_muller<T>(u01<T>(r.x), u01<T>(r.y), &n0, &n1);
+  T* const o = BWD ? dmean : z;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npairs; t += stride) {
+    const uint64_t P = p0 + (uint64_t)t;
+    const int64_t ia = (int64_t)(2 * P - row0), ib = ia + 1;  // local indices of the pair's rows (ia may be -1)
+    const bool va = ia >= 0, vb = ib < n;
+    T nz[4] = {0, 0, 0, 0};
+    if (!noise) {
+      const U4 r = philox4x32_10(P, 0x30000u, key);
+      box_muller<T>(u01<T>(r.x), u01<T>(r.y), &nz[0], &nz[1]);
+      box_muller<T>(u01<T>(r.z), u01<T>(r.w), &nz[2], &nz[3]);
     }
-    const T y0 = mu.a * k + n0, y1 = mu.b * k + n1;
-    T ss = 0;
-    ss += y0 * y0;
-    ss += y1 * y1;
-    // 1 / max(|y|, 1e-12): the 1-ulp hardware reciprocal square root for fp32, the library for fp64
-    T nn = F<T>::sqrt(ss);
-    const bool clamped = nn < (T)1e-12;
-    const T rn = clamped ? (T)1e12 : F<T>::rsqrt(ss);
-    if (!BWD) {
-      store_pair_nt<T>(z, i, y0 * rn, y1 * rn);
+    if (va && vb) {
+      // every array is touched once: non-temporal accesses
+      const RowPair<T> mu = load_rows2_nt<T>(mean, ia);
+      const T ka_ = __builtin_nontemporal_load(kappa + ia), kb_ = __builtin_nontemporal_load(kappa + ib);
+      if (noise) {
+        const RowPair<T> e = load_rows2_nt<T>(noise, ia);
+        nz[0] = e.v[0]; nz[1] = e.v[1]; nz[2] = e.v[2]; nz[3] = e.v[3];
+      }
+      RowPair<T> g = {};
+      if (BWD) g = load_rows2_nt<T>(gz, ia);
+      RowPair<T> r;
+      T dka = 0, dkb = 0;
+      s1_circle_row<T, BWD>(mu.v[0], mu.v[1], ka_, nz[0], nz[1], g.v[0], g.v[1], &r.v[0], &r.v[1], &dka);
+      s1_circle_row<T, BWD>(mu.v[2], mu.v[3], kb_, nz[2], nz[3], g.v[2], g.v[3], &r.v[2], &r.v[3], &dkb);
+      store_rows2_nt<T>(o, ia, r);
+      if (BWD) {
+        __builtin_nontemporal_store(dka, dkappa + ia);
+        __builtin_nontemporal_store(dkb, dkappa + ib);
+      }
     } else {
-      const Pair<T> g = load_pair_nt<T>(gz, i);
-      T yg = 0;
-      yg += y0 * g.a;
-      yg += y1 * g.b;
-      const T t = clamped ? (T)0 : yg * (rn * rn * rn);
-      const T dy0 = g.a * rn - y0 * t;
-      const T dy1 = g.b * rn - y1 * t;
-      store_pair_nt<T>(dmean, i, k * dy0, k * dy1);
-      T dk = 0;
-      dk += mu.a * dy0;
-      dk += mu.b * dy1;
-      __builtin_nontemporal_store(dk, dkappa + i);
+      const int64_t i = va ? ia : ib;  // the call's first row (odd global index) or its last one (even)
+      const int h = va ? 0 : 2;
+      const Pair<T> mu = load_pair_nt<T>(mean, i);
+      const T k = kappa[i];
+      if (noise) {
+        const Pair<T> e = load_pair_nt<T>(noise, i);
+        nz[h] = e.a; nz[h + 1] = e.b;
+      }
+      Pair<T> g = {};
+      if (BWD) g = load_pair_nt<T>(gz, i);
+      T r0, r1, dk = 0;
+      s1_circle_row<T, BWD>(mu.a, mu.b, k, nz[h], nz[h + 1], g.a, g.b, &r0, &r1, &dk);
+      store_pair_nt<T>(o, i, r0, r1);
+      if (BWD) dkappa[i] = dk;
     }
   }
 }
@@ -677,7 +751,7 @@ extern "C" int vmf_s1_projnormal_fwd(const void* mean, const void* kappa, const 
   PhiloxArg key = make_philox_arg(seed, offset, offset_dev);
   // the circle kernel takes one row per thread up to 2^30 rows (backward: 0.87 -> 0.80 ms for 2^27 rows against a
   // 2048-workgroup grid-stride walk; forward unchanged)
-  int grid = vmf_grid_for(n, 256, dim == 2 ? (1 << 22) : 2048);
+  int grid = vmf_grid_for(dim == 2 ? n / 2 + 1 : n, 256, dim == 2 ? (1 << 22) : 2048);
   VMF_DISPATCH_DTYPE(dtype, {
     if (dim == 2 && pair_aligned<T>(mean) && pair_aligned<T>(z) && pair_aligned<T>(noise))
       hipLaunchKernelGGL((s1_projnormal2_kernel<T, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
@@ -701,7 +775,7 @@ extern "C" int vmf_s1_projnormal_bwd(const void* mean, const void* kappa, const 
   PhiloxArg key = make_philox_arg(seed, offset, offset_dev);
   // the circle kernel takes one row per thread up to 2^30 rows (backward: 0.87 -> 0.80 ms for 2^27 rows against a
   // 2048-workgroup grid-stride walk; forward unchanged)
-  int grid = vmf_grid_for(n, 256, dim == 2 ? (1 << 22) : 2048);
+  int grid = vmf_grid_for(dim == 2 ? n / 2 + 1 : n, 256, dim == 2 ? (1 << 22) : 2048);
   VMF_DISPATCH_DTYPE(dtype, {
     if (dim == 2 && pair_aligned<T>(mean) && pair_aligned<T>(gz) && pair_aligned<T>(dmean) && pair_aligned<T>(noise))
       hipLaunchKernelGGL((s1_projnormal2_kernel<T, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,

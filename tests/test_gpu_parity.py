@@ -710,6 +710,10 @@ def test_s1_and_uniform_counter_noise_streams(oracle, tag, dim):
                                          _lib.dtype_code(z), sp), "vmf_s1_projnormal_fwd")
     rows = [row0 + i for i in range(n)]
     noise = _philox_normals(oracle, rows, 0x30000, seed, offset, dim)
+    if dim == 2:
+        # the circle's layout: rows 2p and 2p+1 share call (p, 0x30000): words (0,1) serve the even row, (2,3) the odd one
+        pairs = _philox_normals(oracle, [r >> 1 for r in rows], 0x30000, seed, offset, 4)
+        noise = np.stack([pairs[i, 2 * (r & 1): 2 * (r & 1) + 2] for i, r in enumerate(rows)])
     want = oracle.s1_projnormal_fwd(N(tm).astype(np.float64), N(tk).astype(np.float64), noise)
     tol = 1e-11 if tag == "f64" else 2e-5
     np.testing.assert_allclose(N(z), want, rtol=0, atol=tol)
