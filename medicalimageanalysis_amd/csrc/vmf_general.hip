@@ -548,18 +548,22 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
   }
 }
 
-// ---- narrow rows that do not fill a power-of-two lane group (m = 3 .. 31 except 4, 8, 16; fp32, counter noise) -----
-// The lane-group mapping above gives such rows scalar, guarded element accesses and leaves lanes idle (m = 10: four
-// lanes per row, ten of their sixteen slots used).  Here ONE lane owns a row.  A wave's tile of 128 rows is 128 m
+// ---- narrow rows (m = 3 .. 31 except 8; fp32, counter noise): ONE lane owns a row --------------------------------------
+// The lane-group mapping above gives rows that do not fill a power-of-two group scalar, guarded element accesses and
+// leaves lanes idle (m = 10: four lanes per row, ten of their sixteen slots used).  Here a wave's tile of rows is
 // contiguous floats of mu: it moves between HBM and the wave as a flat array, 16 bytes per lane and access, fully
 // coalesced, and is parked in a wave-private LDS slab; a lane then reads its row from the slab (row stride m words:
-// conflict-free 32-bit reads for odd m, 64-bit reads for m = 2 mod 4), keeps the whole row in registers -- no
-// cross-lane sums at all -- writes z back over it, and the slab leaves as a flat array again.  The mu loads are issued
-// before the rejection phase and land while it runs.  Same counters, same noise, same arithmetic as the kernel above.
+// conflict-free 32-bit reads for odd m, 64-bit reads for even m), keeps the whole row in registers -- no cross-lane sums
+// at all -- writes z back over it, and the slab leaves as a flat array again.  (m = 4: a 16-byte unit is a row, so
+// there is no slab at all.)  The tile's kappa is loaded first and its mu right behind: the memory counter retires loads
+// in order, so phase 1 starts when kappa is there and mu lands while it runs.  kappa and log C_m(kappa) of row
+// lane + 64 s stay in the registers of the lane that phase 2 gives that row, so the only LDS besides the mu slab is the
+// pair of slabs that carries b(kappa) into the rejection phase and (w, 1 - w^2) out of it -- LDS is what bounds the
+// number of resident waves here.  Same counters, same noise, same arithmetic as the kernel above.
 // rows per wave: the rejection phase ends in a tail whose cost is per tile, so the narrowest rows take larger tiles (as in
-// the kernel above); the slab stays near 5-8 KiB per wave.  2^24 rows, lane-group kernel -> this one, forward / backward ms:
-// m = 10: 0.44 / 0.60 -> 0.32 / 0.34; 12: 0.51 / 0.59 -> 0.36 / 0.41; 17: 0.81 / 1.17 -> 0.49 / 0.58; 20: 0.75 / 0.97 ->
-// 0.52 / 0.69; 24: 0.78 / 1.02 -> 0.61 / 0.82; 31: 1.34 / 1.68 -> 0.75 / 1.07
+// the kernel above).  2^24 rows, forward, lane-group kernel -> this one as first written -> now (settled, ms):
+// m = 3: - / 0.189 / 0.140; 4: 0.163 / - / 0.139; 5: - / 0.190 / 0.171; 10: 0.44 / 0.268 / 0.255; 12: 0.51 / 0.307 /
+// 0.285; 16: 0.408 / - / 0.369; 20: 0.75 / 0.45 / 0.45; 31: 1.34 / 0.70 / 0.70
 #ifndef VMF_RL_TILE_WIDE
 #define VMF_RL_TILE_WIDE 128
 #endif
@@ -569,38 +573,49 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
 #ifndef VMF_RL_TILE_WIDER
 #define VMF_RL_TILE_WIDER 64
 #endif
-constexpr int rl_tile(int m) { return m <= 4 ? 384 : (m <= 7 ? 256 : (m <= 16 ? VMF_RL_TILE_WIDE : VMF_RL_TILE_WIDER)); }
-template <int M>
-__global__ __launch_bounds__(WAVES * 64) void vmf_rsample_rowlane_kernel(FwdParams<float> p) {
+#ifndef VMF_RL_KF_MAX
+#define VMF_RL_KF_MAX 16  // widths up to this one load kappa ahead of mu
+#endif
+// waves per workgroup of the forward kernel.  It has no workgroup barrier, so any count works; one-wave workgroups free
+// their LDS and registers as soon as that wave's stores are out instead of when the slowest of four is done (the
+// rejection phase makes tiles finish at different times): 1-2 % at m <= 16, nothing or slightly worse beyond
+#ifndef VMF_RL_WAVES_NARROW
+#define VMF_RL_WAVES_NARROW 1
+#endif
+constexpr int rl_waves(int m) { return m <= 16 ? VMF_RL_WAVES_NARROW : 4; }
+#ifndef VMF_RL_TILE4
+#define VMF_RL_TILE4 384
+#endif
+constexpr int rl_tile(int m) { return m == 4 ? VMF_RL_TILE4 : m <= 4 ? 384 : (m <= 7 ? 256 : (m <= 16 ? VMF_RL_TILE_WIDE : VMF_RL_TILE_WIDER)); }
+template <int M, bool FULL>
+__device__ __forceinline__ void rowlane_tile(const FwdParams<float>& p, const PhiloxKey& key, float* const somw,
+                                             float* const sw, float* const srow, const int64_t tile0, const int ntile_,
+                                             const int lane) {
   using T = float;
   constexpr int RL_TILE = rl_tile(M);
+  const int ntile = FULL ? RL_TILE : ntile_;  // a compile-time constant in the full-tile copy
   constexpr int UNITS = RL_TILE * M / 4;  // 16-byte units of a full tile
   constexpr int UPL = (UNITS + 63) / 64;  // per lane
   constexpr int CHUNKS = (M + 3) / 4;
-  __shared__ T s_wc[WAVES][2][RL_TILE];
-  __shared__ float s_lc[WAVES][RL_TILE], s_kp[WAVES][RL_TILE];
-  __shared__ __align__(16) T s_rows[WAVES][RL_TILE * M];
-  const PhiloxKey key = philox_resolve(p.ka);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  T* const somw = s_wc[wave][0];
-  T* const sw = s_wc[wave][1];
-  float* const slc = s_lc[wave];
-  float* const skp = s_kp[wave];
-  T* const srow = s_rows[wave];
-  const int64_t tile0 = ((int64_t)blockIdx.x * WAVES + wave) * RL_TILE;  // wave-uniform
-  const int64_t left = p.n - tile0;
-  if (left <= 0) return;  // the kernel has no workgroup barrier
-  const int ntile = left < RL_TILE ? (int)left : RL_TILE;
-  // flat 128-bit moves for full tiles of dense, aligned rows; any other layout (views that start mid-allocation, one
-  // shared mean, padded rows) is gathered element by element -- same arithmetic, same bits
-  const bool full = p.dense16 && ntile == RL_TILE;
   const T* const kap_t = p.kappa + tile0 * p.kappa_stride;
   const uint64_t grow0 = p.row0 + (uint64_t)tile0;
   const T* const mu_t = p.mu + tile0 * p.mu_stride;
   T* const z_t = p.z + tile0 * M;
-  // the tile's mu, in flight during phase 1
+  // The tile's concentrations first, then its mu: the memory counter retires loads in order, so a wait for kappa also
+  // waits for every load issued before it -- with kappa in front, phase 1 starts as soon as kappa is there and mu lands
+  // while it runs.
+  constexpr int KPL = RL_TILE / 64;
+  constexpr bool KAPPA_FIRST = M <= VMF_RL_KF_MAX;
+  T kraw[KPL];
+  if (KAPPA_FIRST) {
+#pragma unroll
+    for (int s = 0; s < KPL; ++s) {
+      const int i = lane + 64 * s;
+      kraw[s] = (FULL || i < ntile) ? __builtin_nontemporal_load(kap_t + (int64_t)i * p.kappa_stride) : (T)1;
+    }
+  }
   u32x4 stage[UPL];
-  if (full) {
+  if (FULL) {
 #pragma unroll
     for (int s = 0; s < UPL; ++s) {
       const int q = lane + 64 * s;
@@ -610,15 +625,21 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_rowlane_kernel(FwdPara
   // ---- phase 1: rejection sampler, one row per lane with ballot refill (as in vmf_rsample_fwd_kernel) ----
   const bool sp = p.softplus != 0;
   const bool lp = p.logp != nullptr;
-  for (int i = lane; i < ntile; i += 64) {
-    T sig_;
-    const T kap = kappa_of<T>(kap_t[i * p.kappa_stride], sp, &sig_);
-    if (p.kappa_out) p.kappa_out[tile0 + i] = kap;
-    if (lp) {
-      skp[i] = kap;
-      slc[i] = vmf_log_norm_f32v(p.lc_v, p.lc_lg, p.lc_c0, kap);
+  // kappa and log C_m(kappa) of row lane + 64 s stay in this lane's registers: phase 2 gives the lane that same row
+  T kap_r[KPL], lc_r[KPL];
+#pragma unroll
+  for (int s = 0; s < KPL; ++s) {
+    const int i = lane + 64 * s;
+    kap_r[s] = (T)1;
+    lc_r[s] = (T)0;
+    if (FULL || i < ntile) {
+      T sig_;
+      const T kap = kappa_of<T>(KAPPA_FIRST ? kraw[s] : kap_t[(int64_t)i * p.kappa_stride], sp, &sig_);
+      if (p.kappa_out) p.kappa_out[tile0 + i] = kap;
+      kap_r[s] = kap;
+      if (lp) lc_r[s] = vmf_log_norm_f32v(p.lc_v, p.lc_lg, p.lc_c0, kap);
+      somw[i] = wood_b<T>(kap, M);
     }
-    somw[i] = wood_b<T>(kap, M);
   }
   wave_lds_sync();
 #ifdef VMF_ABLATE_PHASE1  // timing ablation only (w fixed): the rejection phase costs 0.06-0.08 ms per 2^24 rows at any width
@@ -655,8 +676,11 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_rowlane_kernel(FwdPara
     }
   }
 #endif
-  // ---- park the tile's mu in the slab ----
-  if (full) {
+  // ---- park the tile's mu in the slab (m = 4: a 16-byte unit IS a row and unit lane + 64 s is the row phase 2 gives
+  //      this lane, so the rows stay in registers and no slab exists) ----
+  constexpr bool DIRECT = M == 4;
+  if (DIRECT) {
+  } else if (FULL) {
 #pragma unroll
     for (int s = 0; s < UPL; ++s) {
       const int q = lane + 64 * s;
@@ -672,7 +696,16 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_rowlane_kernel(FwdPara
     const int r = sub * 64 + lane;
     if (r < ntile) {
       T mu[M], g[M];
-      if (M % 2 == 0) {
+      if (DIRECT) {
+        if (FULL) {
+          f32x4 v;
+          __builtin_memcpy(&v, &stage[sub], 16);
+          mu[0] = v.x; mu[1] = v.y; mu[2 % M] = v.z; mu[3 % M] = v.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < M; ++e) mu[e] = mu_t[(int64_t)r * p.mu_stride + e];
+        }
+      } else if (M % 2 == 0) {
 #pragma unroll
         for (int e = 0; e < M; e += 2) {
           const f32x2 v = *reinterpret_cast<const f32x2*>(srow + r * M + e);
@@ -722,7 +755,15 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_rowlane_kernel(FwdPara
       z[0] = w - coef * d0;
 #pragma unroll
       for (int e = 1; e < M; ++e) z[e] = f * g[e] + coef_mu * mu[e];
-      if (M % 2 == 0) {
+      if (DIRECT) {
+        if (FULL) {
+          const f32x4 v = {z[0], z[1], z[2 % M], z[3 % M]};
+          store_nt(v, z_t + 4 * r);
+        } else {
+#pragma unroll
+          for (int e = 0; e < M; ++e) z_t[r * M + e] = z[e];
+        }
+      } else if (M % 2 == 0) {
 #pragma unroll
         for (int e = 0; e < M; e += 2) {
           f32x2 v;
@@ -735,12 +776,13 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_rowlane_kernel(FwdPara
       }
       if (lp) {  // <mu, z> through the two small quantities, as in the kernel above
         const T mz = w * mu0 + f * gm - coef * (mu0 * d0 - tail);
-        slc[r] += skp[r] * mz;
+        p.logp[tile0 + r] = lc_r[sub] + kap_r[sub] * mz;
       }
     }
   }
+  if (DIRECT) return;
   wave_lds_sync();
-  if (full) {
+  if (FULL) {
 #pragma unroll
     for (int s = 0; s < UPL; ++s) {
       const int q = lane + 64 * s;
@@ -754,18 +796,42 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_rowlane_kernel(FwdPara
   } else {
     for (int e = lane; e < ntile * M; e += 64) z_t[e] = srow[e];
   }
-  if (lp)
-    for (int i = lane; i < ntile; i += 64) p.logp[tile0 + i] = slc[i];
 }
 
-// widths that take the one-lane-per-row kernels: everything up to VMF_RL_MAX except 4, 8 and 16, whose rows fill their
-// lane group exactly (measured: m = 4 / 8 are 20 % / 10 % slower here, m = 12 -- three of four lanes busy there -- 30 % faster)
-static bool rowlane_ok(int m) { return m >= 3 && m <= VMF_RL_MAX && m != 4 && m != 8 && m != 16; }
+template <int M>
+__global__ __launch_bounds__(rl_waves(M) * 64) void vmf_rsample_rowlane_kernel(FwdParams<float> p) {
+  using T = float;
+  constexpr int RL_TILE = rl_tile(M);
+  constexpr int RL_WAVES = rl_waves(M);
+  __shared__ T s_wc[RL_WAVES][2][RL_TILE];
+  __shared__ __align__(16) T s_rows[RL_WAVES][M == 4 ? 4 : RL_TILE * M];  // (m = 4 keeps its rows in registers)
+  const PhiloxKey key = philox_resolve(p.ka);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t tile0 = ((int64_t)blockIdx.x * RL_WAVES + wave) * RL_TILE;  // wave-uniform
+  const int64_t left = p.n - tile0;
+  if (left <= 0) return;  // the kernel has no workgroup barrier
+  const int ntile = left < RL_TILE ? (int)left : RL_TILE;
+  // flat 128-bit moves for full tiles of dense, aligned rows; any other layout (views that start mid-allocation, one
+  // shared mean, padded rows) is gathered element by element -- same arithmetic, same bits.  Two copies of the body, so
+  // that the full-tile one issues its loads unconditionally and the compiler can count them (see rowlane_tile).
+  if (p.dense16 && ntile == RL_TILE)
+    rowlane_tile<M, true>(p, key, s_wc[wave][0], s_wc[wave][1], s_rows[wave], tile0, ntile, lane);
+  else
+    rowlane_tile<M, false>(p, key, s_wc[wave][0], s_wc[wave][1], s_rows[wave], tile0, ntile, lane);
+}
+
+// widths that take the one-lane-per-row forward kernel: everything up to VMF_RL_MAX except 8, whose rows fill their pair
+// of lanes exactly and measure 3 % faster in the lane-group kernel (2^24 rows, lane-group -> here: m = 4 0.163 -> 0.139 ms,
+// 8 0.215 -> 0.222, 16 0.408 -> 0.369).  The backward kernel keeps the lane groups for 4, 8 and 16.
+static bool rowlane_ok(int m) { return m >= 3 && m <= VMF_RL_MAX && m != 8; }
+static bool rowlane_bwd_ok(int m) { return rowlane_ok(m) && m != 4 && m != 16; }
 static void launch_rowlane(const FwdParams<float>& p, hipStream_t s) {
   const int64_t tiles = (p.n + rl_tile(p.m) - 1) / rl_tile(p.m);
-  const dim3 grid((unsigned)((tiles + WAVES - 1) / WAVES)), block(WAVES * 64);
+  const int waves = rl_waves(p.m);
+  const dim3 grid((unsigned)((tiles + waves - 1) / waves)), block(waves * 64);
   switch (p.m) {
 #define VMF_RL(MM) case MM: hipLaunchKernelGGL((vmf_rsample_rowlane_kernel<MM>), grid, block, 0, s, p); break
+    VMF_RL(4); VMF_RL(8); VMF_RL(16);
     VMF_RL(3); VMF_RL(5); VMF_RL(6); VMF_RL(7); VMF_RL(9); VMF_RL(10); VMF_RL(11); VMF_RL(12); VMF_RL(13); VMF_RL(14);
     VMF_RL(15); VMF_RL(17); VMF_RL(18); VMF_RL(19); VMF_RL(20); VMF_RL(21); VMF_RL(22); VMF_RL(23); VMF_RL(24); VMF_RL(25);
     VMF_RL(26); VMF_RL(27); VMF_RL(28); VMF_RL(29); VMF_RL(30); VMF_RL(31);
@@ -1473,9 +1539,11 @@ static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   const bool pair_ok = m == 2 && !prop_e && !gauss && mu_stride % 2 == 0 && ((uintptr_t)mu % (2 * sizeof(T))) == 0 &&
                        ((uintptr_t)z % (2 * sizeof(T))) == 0;
   if constexpr (sizeof(T) == 4) {
-    // narrow rows of a width that is not a multiple of four, counter noise: one lane per row whatever the layout, so that
-    // a draw does not depend on where a shard's rows start
+    // narrow rows, counter noise: one lane per row whatever the layout, so that a draw does not depend on where a
+    // shard's rows start
     if (rowlane_ok(m) && !prop_e) {
+      VMF_REQUIRE((n + rl_tile(m) - 1) / rl_tile(m) / rl_waves(m) < 0x7fffffff, VMF_ERR_UNSUPPORTED,
+                  "n=%lld rows need more than 2^31 workgroups", (long long)n);
       p.dense16 = mu_stride == m && aligned16(mu) && aligned16(z);
       launch_rowlane(p, s);
       return VMF_OK;
@@ -1564,7 +1632,7 @@ static int rsample_bwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   const int grid = (int)(gb < 1 ? 1 : gb);
   if constexpr (sizeof(T) == 4) {
     // narrow rows of a width that is not a multiple of four, regenerated noise: one lane per row whatever the layout
-    if (rowlane_ok(m) && !gauss) {
+    if (rowlane_bwd_ok(m) && !gauss) {
       VMF_REQUIRE((n + rl_tile(m) - 1) / rl_tile(m) / WAVES < 0x7fffffff, VMF_ERR_UNSUPPORTED,
                   "n=%lld rows need more than 2^31 workgroups", (long long)n);
       p.dense16 = mu_stride == m && aligned16(mu) && aligned16(gz) && aligned16(dmu);

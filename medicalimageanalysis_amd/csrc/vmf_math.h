@@ -573,23 +573,35 @@ VMF_HD bool wood_try(T a, T b, T d, int m, T e, T uacc, T* w, T* omw) {
 template <typename T>
 __device__ __forceinline__ bool wood_try_counter(T b, int m, T U, T V, T uacc, T* w, T* omw, T* c2) {
   T sq = (T)1, q = (T)0;
-  if (m > 2) {
+  if (m == 4) {  // U^(2/(m-2)) = U: no logarithm, and 1 - U is exact
+    q = U;
+    sq = (T)1 - U;
+  } else if (m == 3) {  // U^2
+    q = U * U;
+    sq = ((T)1 - U) * ((T)1 + U);
+  } else if (m > 2) {
     const T t = (T)2 / (T)(m - 2) * F<T>::log2(U);
     sq = F<T>::one_minus_exp2(t);  // 1 - U^(2/(m-2))
     q = F<T>::exp2(t);
   }
   const T rt = F<T>::sqrt(sq);
   const T c = rt * F<T>::cos2pi(V);
-  T omc = (T)1 - c;
-  if (m <= 4) {  // from m = 5 on the density vanishes at w = -1 fast enough that no draw comes near it
+  const T opc = (T)1 + c;
+  T omc = (T)1 - c, opa = opc;
+  if (m <= 4) {  // from m = 5 on the density vanishes at w = -1 and at w = 1 fast enough that no draw comes near them
     const T Vf = V > (T)0.5 ? (T)1 - V : V;  // sin^2 pi V = sin^2 pi Vf, from a small argument at both ends
     const T sh = F<T>::sin2pi((T)0.5 * Vf);
-    omc = q * F<T>::rcp((T)1 + rt) + (T)2 * rt * sh * sh;
+    const T r1 = q * F<T>::rcp((T)1 + rt);  // 1 - r
+    omc = r1 + (T)2 * rt * sh * sh;
+    // and the mirror image for the other pole: 1 + c = (1 - r) + 2 r cos^2(pi V), the cosine as the sine of the exact
+    // difference 1/4 - Vf/2 (revolutions).  It feeds the outputs only (1 - w, 1 - w^2: a w within 1e-7 of +1 keeps the
+    // digits of its tangent component); the accept test below takes the plain 1 + c, whose absolute error is all it sees.
+    const T chh = F<T>::sin2pi((T)0.25 - (T)0.5 * Vf);
+    opa = r1 + (T)2 * rt * chh * chh;
   }
-  const T opc = (T)1 + c;
   const T den = (T)1 - (T)0.5 * ((T)1 - b) * opc;
   const T rden = F<T>::rcp(den);
-  *omw = b * opc * rden;
+  *omw = b * opa * rden;
   *w = (T)1 - *omw;
   *c2 = *omw * (omc * rden);
   const T s = (T)0.5 * ((T)1 - b) * c * rden;

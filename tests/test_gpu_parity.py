@@ -1430,7 +1430,10 @@ def test_general_m3_fp32_keeps_its_digits_at_the_south_pole():
     assert int(pole.sum()) >= 5, int(pole.sum())
     err = (z32 - z64).abs().amax(dim=1)
     assert float(err[pole].max()) < 5e-6, float(err[pole].max())
-    assert float(err[same].max()) < 2e-5, float(err[same].max())
+    # (both poles: a w within 1e-7 of +1 kept only half the digits of its tangent component while 1 + c was formed by
+    #  subtraction -- 6e-5 on one row of this draw; measured now: 1.2e-6)
+    assert float(err[same].max()) < 5e-6, float(err[same].max())
+    record_margin("general_m3_fp32_vs_fp64_max_abs_z", [float(err[same].max())], [5e-6])
     assert float((z32.norm(dim=1) - 1).abs().max()) < 1e-5
 
 

@@ -5,7 +5,7 @@
 set -u
 tag=${1:-narrow}
 root=$GRAFT_REPO_ROOT
-S=10:24,12:24,31:24
+S=${SHAPES:-10:24,12:24,31:24}
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_$tag -- python3 $root/tools/bench_narrow.py --shapes $S --s1 0 > $root/gpurun_out/bench_$tag.md 2> $root/gpurun_out/bench_$tag.err || exit 1
 pass() {
