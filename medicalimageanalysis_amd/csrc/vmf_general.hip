@@ -562,8 +562,8 @@ void vmf_rsample_fwd_kernel(FwdParams<T> p) {
 // number of resident waves here.  Same counters, same noise, same arithmetic as the kernel above.
 // rows per wave: the rejection phase ends in a tail whose cost is per tile, so the narrowest rows take larger tiles (as in
 // the kernel above).  2^24 rows, forward, lane-group kernel -> this one as first written -> now (settled, ms):
-// m = 3: - / 0.189 / 0.140; 4: 0.163 / - / 0.139; 5: - / 0.190 / 0.171; 10: 0.44 / 0.268 / 0.255; 12: 0.51 / 0.307 /
-// 0.285; 16: 0.408 / - / 0.369; 20: 0.75 / 0.45 / 0.45; 31: 1.34 / 0.70 / 0.70
+// m = 3: - / 0.189 / 0.130; 4: 0.163 / - / 0.139; 5: - / 0.190 / 0.163; 10: 0.44 / 0.268 / 0.250; 12: 0.51 / 0.307 /
+// 0.287; 16: 0.408 / - / 0.370; 20: 0.75 / 0.45 / 0.45; 31: 1.34 / 0.70 / 0.70
 #ifndef VMF_RL_TILE_WIDE
 #define VMF_RL_TILE_WIDE 128
 #endif
@@ -587,23 +587,53 @@ constexpr int rl_waves(int m) { return m <= 16 ? VMF_RL_WAVES_NARROW : 4; }
 #define VMF_RL_TILE4 384
 #endif
 constexpr int rl_tile(int m) { return m == 4 ? VMF_RL_TILE4 : m <= 4 ? 384 : (m <= 7 ? 256 : (m <= 16 ? VMF_RL_TILE_WIDE : VMF_RL_TILE_WIDER)); }
+// Forward tiles: the rejection phase runs over the whole wave tile (its tail costs a few wave-iterations per TILE, so
+// the tile wants to be large), the mu slab holds one sub-tile at a time (it is what bounds the resident waves, so it
+// wants to be small): rl_fwd_tile rows per wave, rl_fwd_sub rows per slab.  Settled times for 2^24 rows, one slab of the
+// whole tile (384 rows at m = 3, 256 at 5, 128 from 9 on) -> sub-tiled: m = 3 0.135 -> 0.130 ms (512 / 128: the same),
+// 5 0.174 -> 0.163, 10 0.254 -> 0.250 (256 / 64; 384 rows: 0.28); 12 0.287 -> 0.295, 16 0.370 -> 0.397: from m = 12 on
+// the whole-tile slab of 128 rows stays.
+#ifndef VMF_RLF_TILE_S
+#define VMF_RLF_TILE_S 384  // m = 3, 5, 6, 7
+#endif
+#ifndef VMF_RLF_SUB_S
+#define VMF_RLF_SUB_S 128
+#endif
+#ifndef VMF_RLF_TILE_M
+#define VMF_RLF_TILE_M 256  // m = 9, 10, 11
+#endif
+#ifndef VMF_RLF_SUB_M
+#define VMF_RLF_SUB_M 64
+#endif
+constexpr int rl_fwd_tile(int m) {
+  return m == 4 ? VMF_RL_TILE4 : (m <= 7 ? VMF_RLF_TILE_S : (m <= 11 ? VMF_RLF_TILE_M : (m <= 16 ? VMF_RL_TILE_WIDE : VMF_RL_TILE_WIDER)));
+}
+constexpr int rl_fwd_sub(int m) {
+  return m == 4 ? VMF_RL_TILE4 : (m <= 7 ? VMF_RLF_SUB_S : (m <= 11 ? VMF_RLF_SUB_M : (m <= 16 ? VMF_RL_TILE_WIDE : VMF_RL_TILE_WIDER)));
+}
+
 template <int M, bool FULL>
 __device__ __forceinline__ void rowlane_tile(const FwdParams<float>& p, const PhiloxKey& key, float* const somw,
                                              float* const sw, float* const srow, const int64_t tile0, const int ntile_,
                                              const int lane) {
   using T = float;
-  constexpr int RL_TILE = rl_tile(M);
+  constexpr int RL_TILE = rl_fwd_tile(M), SUB = rl_fwd_sub(M), NSUB = RL_TILE / SUB, SPL = SUB / 64;
+  static_assert(RL_TILE % SUB == 0 && SUB % 64 == 0, "a wave tile is a whole number of slabs of whole 64-row steps");
   const int ntile = FULL ? RL_TILE : ntile_;  // a compile-time constant in the full-tile copy
-  constexpr int UNITS = RL_TILE * M / 4;  // 16-byte units of a full tile
+  constexpr int UNITS = SUB * M / 4;      // 16-byte units of a full sub-tile
   constexpr int UPL = (UNITS + 63) / 64;  // per lane
   constexpr int CHUNKS = (M + 3) / 4;
+  // m = 4: a 16-byte unit IS a row and unit lane + 64 s is the row phase 2 gives this lane, so the rows stay in
+  // registers and no slab exists
+  constexpr bool DIRECT = M == 4;
+  static_assert(!DIRECT || NSUB == 1, "the slab-free shape keeps its whole tile in registers");
   const T* const kap_t = p.kappa + tile0 * p.kappa_stride;
   const uint64_t grow0 = p.row0 + (uint64_t)tile0;
   const T* const mu_t = p.mu + tile0 * p.mu_stride;
   T* const z_t = p.z + tile0 * M;
-  // The tile's concentrations first, then its mu: the memory counter retires loads in order, so a wait for kappa also
-  // waits for every load issued before it -- with kappa in front, phase 1 starts as soon as kappa is there and mu lands
-  // while it runs.
+  // The tile's concentrations first, then the first sub-tile of mu: the memory counter retires loads in order, so a wait
+  // for kappa also waits for every load issued before it -- with kappa in front, phase 1 starts as soon as kappa is
+  // there and mu lands while it runs.
   constexpr int KPL = RL_TILE / 64;
   constexpr bool KAPPA_FIRST = M <= VMF_RL_KF_MAX;
   T kraw[KPL];
@@ -642,7 +672,7 @@ __device__ __forceinline__ void rowlane_tile(const FwdParams<float>& p, const Ph
     }
   }
   wave_lds_sync();
-#ifdef VMF_ABLATE_PHASE1  // timing ablation only (w fixed): the rejection phase costs 0.06-0.08 ms per 2^24 rows at any width
+#ifdef VMF_ABLATE_PHASE1  // timing ablation only (w fixed)
   for (int i = lane; i < ntile; i += 64) { sw[i] = 0.5f; somw[i] = 0.75f; }
 #else
   {
@@ -676,135 +706,155 @@ __device__ __forceinline__ void rowlane_tile(const FwdParams<float>& p, const Ph
     }
   }
 #endif
-  // ---- park the tile's mu in the slab (m = 4: a 16-byte unit IS a row and unit lane + 64 s is the row phase 2 gives
-  //      this lane, so the rows stay in registers and no slab exists) ----
-  constexpr bool DIRECT = M == 4;
-  if (DIRECT) {
-  } else if (FULL) {
-#pragma unroll
-    for (int s = 0; s < UPL; ++s) {
-      const int q = lane + 64 * s;
-      if (UNITS % 64 == 0 || q < UNITS) reinterpret_cast<u32x4*>(srow)[q] = stage[s];
-    }
-  } else {
-    for (int e = lane; e < ntile * M; e += 64) srow[e] = mu_t[(e / M) * p.mu_stride + e % M];
-  }
   wave_lds_sync();
-  // ---- phase 2: one row per lane ----
+  // ---- phase 2, one sub-tile at a time: park its mu in the slab, send for the next sub-tile's mu (into the registers
+  //      just emptied: it lands while this one computes), one row per lane, the slab out as a flat array ----
 #pragma unroll
-  for (int sub = 0; sub < RL_TILE / 64; ++sub) {
-    const int r = sub * 64 + lane;
-    if (r < ntile) {
-      T mu[M], g[M];
-      if (DIRECT) {
-        if (FULL) {
+  for (int sub = 0; sub < NSUB; ++sub) {
+    const int rows0 = sub * SUB;
+    const int left = ntile - rows0;
+    const int nsub = FULL ? SUB : (left < SUB ? left : SUB);
+    if (!FULL && nsub <= 0) break;  // wave-uniform
+    const T* const mu_s = mu_t + (int64_t)rows0 * p.mu_stride;
+    T* const z_s = z_t + rows0 * M;
+    if (!DIRECT) {
+      if (FULL) {
+#pragma unroll
+        for (int s = 0; s < UPL; ++s) {
+          const int q = lane + 64 * s;
+          if (UNITS % 64 == 0 || q < UNITS) reinterpret_cast<u32x4*>(srow)[q] = stage[s];
+        }
+      } else {
+        for (int e = lane; e < nsub * M; e += 64) srow[e] = mu_s[(e / M) * p.mu_stride + e % M];
+      }
+      wave_lds_sync();
+      if (FULL && sub + 1 < NSUB) {
+#pragma unroll
+        for (int s = 0; s < UPL; ++s) {
+          const int q = lane + 64 * s;
+          if (UNITS % 64 == 0 || q < UNITS)
+            stage[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(mu_s + SUB * M) + q);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+      const int rl = j * 64 + lane;  // row inside the sub-tile
+      const int r = rows0 + rl;      // row inside the tile
+      if (FULL || rl < nsub) {
+        T mu[M], g[M];
+        if (DIRECT) {
+          if (FULL) {
+            f32x4 v;
+            __builtin_memcpy(&v, &stage[j % UPL], 16);
+            mu[0] = v.x; mu[1] = v.y; mu[2 % M] = v.z; mu[3 % M] = v.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < M; ++e) mu[e] = mu_s[(int64_t)rl * p.mu_stride + e];
+          }
+        } else if (M % 2 == 0) {
+#pragma unroll
+          for (int e = 0; e < M; e += 2) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(srow + rl * M + e);
+            mu[e] = v.x; mu[e + 1] = v.y;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < M; ++e) mu[e] = srow[rl * M + e];
+        }
+        // normals of elements 4c .. 4c+3 from Philox(row, SLOT_GAUSS + c), element 0 carries none
+#pragma unroll
+        for (int c = 0; c < CHUNKS; ++c) {
+          const U4 rr = philox4x32_10(grow0 + (uint64_t)r, SLOT_GAUSS + (uint32_t)c, key);
+          T n0, n1;
+          box_muller<T>(u01<T>(rr.x), u01<T>(rr.y), &n0, &n1);
+          if (4 * c < M) g[4 * c] = n0;
+          if (4 * c + 1 < M) g[4 * c + 1] = n1;
+          if (4 * c + 2 < M) {
+            box_muller<T>(u01<T>(rr.z), u01<T>(rr.w), &n0, &n1);
+            g[4 * c + 2] = n0;
+            if (4 * c + 3 < M) g[4 * c + 3] = n1;
+          }
+        }
+        g[0] = (T)0;
+        T gg = 0, tail = 0, gm = 0;
+#pragma unroll
+        for (int e = 1; e < M; ++e) {
+          gg += g[e] * g[e];
+          tail += mu[e] * mu[e];
+          gm += g[e] * mu[e];
+        }
+        T mu0 = mu[0];
+        const T inv = p.normalize ? F<T>::rsqrt(tail + mu0 * mu0) : (T)1;
+        mu0 *= inv;
+        gm *= inv;
+        const T d0 = (T)1 - mu0;
+        tail *= inv * inv;                // |mu|^2 without its first element
+        const T dd = d0 * d0 + tail;      // |e1 - mu|^2
+        const T w = sw[r];
+        T c2 = somw[r];
+        c2 = c2 < (T)1e-10 ? (T)1e-10 : c2;
+        const T f = F<T>::sqrt(c2) * F<T>::rsqrt(gg);
+        const T zd = w * d0 - f * gm;
+        const T coef = dd > (T)1e-30 ? (T)2 * zd * F<T>::rcp(dd) : (T)0;
+        const T coef_mu = coef * inv;
+        T z[M];
+        z[0] = w - coef * d0;
+#pragma unroll
+        for (int e = 1; e < M; ++e) z[e] = f * g[e] + coef_mu * mu[e];
+        if (DIRECT) {
+          if (FULL) {
+            const f32x4 v = {z[0], z[1], z[2 % M], z[3 % M]};
+            store_nt(v, z_s + 4 * rl);
+          } else {
+#pragma unroll
+            for (int e = 0; e < M; ++e) z_s[rl * M + e] = z[e];
+          }
+        } else if (M % 2 == 0) {
+#pragma unroll
+          for (int e = 0; e < M; e += 2) {
+            f32x2 v;
+            v.x = z[e]; v.y = z[e + 1];
+            *reinterpret_cast<f32x2*>(srow + rl * M + e) = v;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < M; ++e) srow[rl * M + e] = z[e];
+        }
+        if (lp) {  // <mu, z> through the two small quantities, as in the kernel above
+          const T mz = w * mu0 + f * gm - coef * (mu0 * d0 - tail);
+          p.logp[tile0 + r] = lc_r[sub * SPL + j] + kap_r[sub * SPL + j] * mz;
+        }
+      }
+    }
+    if (DIRECT) continue;
+    wave_lds_sync();
+    if (FULL) {
+#pragma unroll
+      for (int s = 0; s < UPL; ++s) {
+        const int q = lane + 64 * s;
+        if (UNITS % 64 == 0 || q < UNITS) {
           f32x4 v;
-          __builtin_memcpy(&v, &stage[sub], 16);
-          mu[0] = v.x; mu[1] = v.y; mu[2 % M] = v.z; mu[3 % M] = v.w;
-        } else {
-#pragma unroll
-          for (int e = 0; e < M; ++e) mu[e] = mu_t[(int64_t)r * p.mu_stride + e];
-        }
-      } else if (M % 2 == 0) {
-#pragma unroll
-        for (int e = 0; e < M; e += 2) {
-          const f32x2 v = *reinterpret_cast<const f32x2*>(srow + r * M + e);
-          mu[e] = v.x; mu[e + 1] = v.y;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < M; ++e) mu[e] = srow[r * M + e];
-      }
-      // normals of elements 4c .. 4c+3 from Philox(row, SLOT_GAUSS + c), element 0 carries none
-#pragma unroll
-      for (int c = 0; c < CHUNKS; ++c) {
-        const U4 rr = philox4x32_10(grow0 + (uint64_t)r, SLOT_GAUSS + (uint32_t)c, key);
-        T n0, n1;
-        box_muller<T>(u01<T>(rr.x), u01<T>(rr.y), &n0, &n1);
-        if (4 * c < M) g[4 * c] = n0;
-        if (4 * c + 1 < M) g[4 * c + 1] = n1;
-        if (4 * c + 2 < M) {
-          box_muller<T>(u01<T>(rr.z), u01<T>(rr.w), &n0, &n1);
-          g[4 * c + 2] = n0;
-          if (4 * c + 3 < M) g[4 * c + 3] = n1;
+          const u32x4 raw = reinterpret_cast<const u32x4*>(srow)[q];
+          __builtin_memcpy(&v, &raw, 16);
+          store_nt(v, z_s + 4 * q);
         }
       }
-      g[0] = (T)0;
-      T gg = 0, tail = 0, gm = 0;
-#pragma unroll
-      for (int e = 1; e < M; ++e) {
-        gg += g[e] * g[e];
-        tail += mu[e] * mu[e];
-        gm += g[e] * mu[e];
-      }
-      T mu0 = mu[0];
-      const T inv = p.normalize ? F<T>::rsqrt(tail + mu0 * mu0) : (T)1;
-      mu0 *= inv;
-      gm *= inv;
-      const T d0 = (T)1 - mu0;
-      tail *= inv * inv;                // |mu|^2 without its first element
-      const T dd = d0 * d0 + tail;      // |e1 - mu|^2
-      const T w = sw[r];
-      T c2 = somw[r];
-      c2 = c2 < (T)1e-10 ? (T)1e-10 : c2;
-      const T f = F<T>::sqrt(c2) * F<T>::rsqrt(gg);
-      const T zd = w * d0 - f * gm;
-      const T coef = dd > (T)1e-30 ? (T)2 * zd * F<T>::rcp(dd) : (T)0;
-      const T coef_mu = coef * inv;
-      T z[M];
-      z[0] = w - coef * d0;
-#pragma unroll
-      for (int e = 1; e < M; ++e) z[e] = f * g[e] + coef_mu * mu[e];
-      if (DIRECT) {
-        if (FULL) {
-          const f32x4 v = {z[0], z[1], z[2 % M], z[3 % M]};
-          store_nt(v, z_t + 4 * r);
-        } else {
-#pragma unroll
-          for (int e = 0; e < M; ++e) z_t[r * M + e] = z[e];
-        }
-      } else if (M % 2 == 0) {
-#pragma unroll
-        for (int e = 0; e < M; e += 2) {
-          f32x2 v;
-          v.x = z[e]; v.y = z[e + 1];
-          *reinterpret_cast<f32x2*>(srow + r * M + e) = v;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < M; ++e) srow[r * M + e] = z[e];
-      }
-      if (lp) {  // <mu, z> through the two small quantities, as in the kernel above
-        const T mz = w * mu0 + f * gm - coef * (mu0 * d0 - tail);
-        p.logp[tile0 + r] = lc_r[sub] + kap_r[sub] * mz;
-      }
+    } else {
+      for (int e = lane; e < nsub * M; e += 64) z_s[e] = srow[e];
     }
-  }
-  if (DIRECT) return;
-  wave_lds_sync();
-  if (FULL) {
-#pragma unroll
-    for (int s = 0; s < UPL; ++s) {
-      const int q = lane + 64 * s;
-      if (UNITS % 64 == 0 || q < UNITS) {
-        f32x4 v;
-        const u32x4 raw = reinterpret_cast<const u32x4*>(srow)[q];
-        __builtin_memcpy(&v, &raw, 16);
-        store_nt(v, z_t + 4 * q);
-      }
-    }
-  } else {
-    for (int e = lane; e < ntile * M; e += 64) z_t[e] = srow[e];
+    wave_lds_sync();  // the slab is rewritten by the next sub-tile
   }
 }
 
+// (asking for 8 waves per SIMD -- 64 registers -- spills at m = 10 and measures 2 % slower than the 66 it takes)
 template <int M>
 __global__ __launch_bounds__(rl_waves(M) * 64) void vmf_rsample_rowlane_kernel(FwdParams<float> p) {
   using T = float;
-  constexpr int RL_TILE = rl_tile(M);
+  constexpr int RL_TILE = rl_fwd_tile(M);
   constexpr int RL_WAVES = rl_waves(M);
   __shared__ T s_wc[RL_WAVES][2][RL_TILE];
-  __shared__ __align__(16) T s_rows[RL_WAVES][M == 4 ? 4 : RL_TILE * M];  // (m = 4 keeps its rows in registers)
+  __shared__ __align__(16) T s_rows[RL_WAVES][M == 4 ? 4 : rl_fwd_sub(M) * M];  // (m = 4 keeps its rows in registers)
   const PhiloxKey key = philox_resolve(p.ka);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t tile0 = ((int64_t)blockIdx.x * RL_WAVES + wave) * RL_TILE;  // wave-uniform
@@ -826,7 +876,7 @@ __global__ __launch_bounds__(rl_waves(M) * 64) void vmf_rsample_rowlane_kernel(F
 static bool rowlane_ok(int m) { return m >= 3 && m <= VMF_RL_MAX && m != 8; }
 static bool rowlane_bwd_ok(int m) { return rowlane_ok(m) && m != 4 && m != 16; }
 static void launch_rowlane(const FwdParams<float>& p, hipStream_t s) {
-  const int64_t tiles = (p.n + rl_tile(p.m) - 1) / rl_tile(p.m);
+  const int64_t tiles = (p.n + rl_fwd_tile(p.m) - 1) / rl_fwd_tile(p.m);
   const int waves = rl_waves(p.m);
   const dim3 grid((unsigned)((tiles + waves - 1) / waves)), block(waves * 64);
   switch (p.m) {
@@ -1542,7 +1592,7 @@ static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
     // narrow rows, counter noise: one lane per row whatever the layout, so that a draw does not depend on where a
     // shard's rows start
     if (rowlane_ok(m) && !prop_e) {
-      VMF_REQUIRE((n + rl_tile(m) - 1) / rl_tile(m) / rl_waves(m) < 0x7fffffff, VMF_ERR_UNSUPPORTED,
+      VMF_REQUIRE((n + rl_fwd_tile(m) - 1) / rl_fwd_tile(m) / rl_waves(m) < 0x7fffffff, VMF_ERR_UNSUPPORTED,
                   "n=%lld rows need more than 2^31 workgroups", (long long)n);
       p.dense16 = mu_stride == m && aligned16(mu) && aligned16(z);
       launch_rowlane(p, s);

@@ -96,4 +96,6 @@ for r in range(a.rounds):
         torch.cuda.synchronize()
         res[name].append(float(np.mean([s.elapsed_time(e) for s, e in evs])))
 for name, v in res.items():
-    print(f"{name:8s} mean {np.mean(v):.4f} ms  rounds " + " ".join(f"{x:.4f}" for x in v), flush=True)
+    # the GPU takes tens of milliseconds of load to settle (the first rounds run 5-15 % slower): the last half counts
+    print(f"{name:8s} settled {np.mean(v[len(v) // 2:]):.4f} ms  mean {np.mean(v):.4f}  rounds "
+          + " ".join(f"{x:.4f}" for x in v), flush=True)

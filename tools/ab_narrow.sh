@@ -4,5 +4,5 @@
 ms=$1; shift
 for m in $ms; do
   echo "== m=$m"
-  timeout -k 10 120 python tools/ab_libs.py "$@" --m $m --rows 16777216 --rounds 3 --steps 20 --no-log-prob || exit 1
+  timeout -k 10 120 python tools/ab_libs.py "$@" --m $m --rows 16777216 --rounds ${ROUNDS:-8} --steps 30 --no-log-prob || exit 1
 done

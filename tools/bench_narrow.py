@@ -18,7 +18,7 @@ from medicalimageanalysis_amd import _lib  # noqa: E402
 DEV = torch.device("cuda:0")
 
 
-def timeit(fn, reps=20, warm=10):
+def timeit(fn, reps=30, warm=60):  # (the GPU needs tens of milliseconds of load to settle)
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
