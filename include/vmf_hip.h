@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VMF_HIP_VERSION 140
+#define VMF_HIP_VERSION 141
 
 typedef void* vmf_stream_t; /* hipStream_t */
 
@@ -290,6 +290,15 @@ int vmf_latent_loss_bwd(const void* z, const void* labels, const void* grad_mean
  * afterwards.  The reference is single-device (model/train.py:36-37) and has no counterpart. */
 #define VMF_ALLREDUCE_MAX_SCALARS 64
 int vmf_allreduce_scalars(void* comm, double* buf, int count, vmf_stream_t stream);
+
+/* ---- device-resident noise counter ----------------------------------------------------------------------
+ * Every sampling entry point takes `offset_dev`, a device-resident 64-bit counter added to `offset` inside the kernel
+ * (the host arguments of a launch captured into a HIP graph are frozen; with the counter on the device every replay
+ * draws fresh noise).  One sampling call = one ticket: snapshot[0] = counter[0]; counter[0] += 1 -- in ONE launch on
+ * `stream` (the two tensor operations it replaces were two).  The snapshot is what the call's forward and backward
+ * pass as `offset_dev`.  The reference draws from torch's global generator (sampler/von_mises_fisher.py:56,75) and
+ * has no counterpart. */
+int vmf_philox_ticket(int64_t* counter, int64_t* snapshot, vmf_stream_t stream);
 
 /* Every compute entry point opens a marker range of its own name when the environment has VMF_ROCTX=1
  * (`rocprofv3 --marker-trace`); no other observable state. */

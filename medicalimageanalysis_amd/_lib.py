@@ -47,6 +47,7 @@ _PROTOS = {
     "vmf_kl_fwd": [_P, _P, _P, _P, _D, _I64, _I, _I, _P],
     "vmf_kl_fwd_static": [_P, _P, _P, _D, _I64, _I, _I, _P],
     "vmf_allreduce_scalars": [_P, _P, _I, _P],
+    "vmf_philox_ticket": [_P, _P, _P],
     "vmf_kl_bwd": [_P, _P, _I64, _D, _P, _I64, _I, _I, _P],
     "vmf_rsample_fwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _I, _P, _I, _U64, _U64, _U64, _P,
                         _I, _I, _P],

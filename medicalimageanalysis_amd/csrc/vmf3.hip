@@ -101,6 +101,22 @@ extern "C" int vmf_allreduce_scalars(void* comm, double* buf, int count, vmf_str
   return VMF_OK;
 }
 
+// ---- one ticket of the device-resident noise counter -----------------------------------------------------
+__global__ void philox_ticket_kernel(int64_t* __restrict__ counter, int64_t* __restrict__ snapshot) {
+  if (threadIdx.x == 0) {
+    const int64_t v = *counter;
+    *snapshot = v;
+    *counter = (int64_t)((uint64_t)v + 1u);
+  }
+}
+extern "C" int vmf_philox_ticket(int64_t* counter, int64_t* snapshot, vmf_stream_t stream) {
+  VMF_RANGE("vmf_philox_ticket");
+  VMF_REQUIRE(counter && snapshot && counter != snapshot, VMF_ERR_BAD_ARG,
+              "vmf_philox_ticket: counter and snapshot must be two device addresses");
+  hipLaunchKernelGGL(philox_ticket_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, snapshot);
+  return vmf_check_launch("vmf_philox_ticket");
+}
+
 extern "C" int vmf_version(void) { return VMF_HIP_VERSION; }
 extern "C" const char* vmf_last_error_string(void) { return g_err; }
 

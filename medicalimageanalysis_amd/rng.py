@@ -66,8 +66,11 @@ class PhiloxGenerator:
                 o = self.offset
                 self.offset = (self.offset + 1) & 0xFFFFFFFFFFFFFFFF
                 return self.seed, o, None
-            snap = self._dev_counter.clone()
-            self._dev_counter.add_(1)
+            # snapshot = counter; counter += 1 as ONE launch of the library (a clone and an in-place add were two)
+            from . import _lib
+            snap = torch.empty_like(self._dev_counter)
+            _lib.check(_lib.lib().vmf_philox_ticket(_lib.ptr(self._dev_counter), _lib.ptr(snap),
+                                                    _lib.stream_ptr(self._dev_counter.device)), "vmf_philox_ticket")
             return self.seed, 0, snap
 
     def get_state(self):

@@ -122,7 +122,7 @@ def close_vmf3(z, z_ref, tag, loc, scale, u, eps, ss=(), name="vmf3"):
 
 def test_library_loaded_is_in_tree():
     assert os.path.dirname(_lib.library_path()).endswith("medicalimageanalysis_amd")
-    assert _lib.lib().vmf_version() == 140
+    assert _lib.lib().vmf_version() == 141
 
 
 # ---- VonMisesFisher3D ---------------------------------------------------------------------------------------
@@ -1786,6 +1786,20 @@ def test_host_counter_refuses_capture():
     assert (seed, off) == (1, 0) and int(dev_off.item()) == 0 and gen.get_state()["offset"] == 1
     gen.set_state({"seed": 3, "offset": (1 << 64) - 1})       # wraps like the host counter
     assert gen.ticket(DEV)[2].item() == -1 and gen.get_state()["offset"] == 0
+
+
+def test_philox_ticket_is_one_launch_snapshot_and_advance():
+    lib, sp = _lib.lib(), _lib.stream_ptr(DEV)
+    ctr = torch.tensor([41], dtype=torch.int64, device=DEV)
+    snaps = [torch.full((1,), -7, dtype=torch.int64, device=DEV) for _ in range(3)]
+    for s in snaps:
+        _lib.check(lib.vmf_philox_ticket(_lib.ptr(ctr), _lib.ptr(s), sp), "vmf_philox_ticket")
+    assert [int(s.item()) for s in snaps] == [41, 42, 43] and int(ctr.item()) == 44
+    ctr.fill_(-1)  # 2^64 - 1 wraps to 0
+    _lib.check(lib.vmf_philox_ticket(_lib.ptr(ctr), _lib.ptr(snaps[0]), sp), "vmf_philox_ticket")
+    assert int(snaps[0].item()) == -1 and int(ctr.item()) == 0
+    assert lib.vmf_philox_ticket(_lib.ptr(ctr), _lib.ptr(ctr), sp) == -1
+    assert lib.vmf_philox_ticket(None, _lib.ptr(ctr), sp) == -1
 
 
 def test_device_counter_draws_equal_host_counter_draws():

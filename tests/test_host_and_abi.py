@@ -25,7 +25,7 @@ def test_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(h, name), name
     lib = _lib.lib()
-    assert lib.vmf_version() == 140
+    assert lib.vmf_version() == 141
     # argument errors are reported without touching a GPU
     assert lib.vmf_rsample_fwd(None, 64, None, 1, None, None, None, None, None, None, -1, 64, None, None, 0, None, 64, 0, 0, 0, None, 0,
                                0, None) == -1
