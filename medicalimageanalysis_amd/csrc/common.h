@@ -453,6 +453,26 @@ __device__ __forceinline__ void store_pair_nt(T* base, int64_t i, T a, T b) {
   __builtin_nontemporal_store(v, reinterpret_cast<V2*>(base) + i);
 }
 
+template <typename T>
+struct RowPair {  // two rows of two values
+  T v[4];
+};
+// streaming (non-temporal) access to two rows at once, aligned to one row only
+template <typename T>
+__device__ __forceinline__ RowPair<T> load_rows2_nt(const T* base, int64_t row) {
+  typedef T V4 __attribute__((ext_vector_type(4), aligned(2 * sizeof(T))));
+  const V4 v = __builtin_nontemporal_load(reinterpret_cast<const V4*>(base + 2 * row));
+  RowPair<T> r;
+  r.v[0] = v.x; r.v[1] = v.y; r.v[2] = v.z; r.v[3] = v.w;
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void store_rows2_nt(T* base, int64_t row, const RowPair<T>& r) {
+  typedef T V4 __attribute__((ext_vector_type(4), aligned(2 * sizeof(T))));
+  const V4 v = {r.v[0], r.v[1], r.v[2], r.v[3]};
+  __builtin_nontemporal_store(v, reinterpret_cast<V4*>(base + 2 * row));
+}
+
 // 16-byte-aligned group of four values (one 128-bit access for float, two for double)
 template <typename T>
 struct alignas(sizeof(T) * 4 > 16 ? 16 : sizeof(T) * 4) Vec4 {

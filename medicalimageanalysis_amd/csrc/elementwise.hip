@@ -635,25 +635,6 @@ __global__ __launch_bounds__(256) void s1_projnormal_kernel(const T* __restrict_
 // here) and ONE Philox call for both rows' Box-Muller pairs.  A call whose
 // first or last row has no partner in the call (odd row offset, odd count) handles that row alone with 64-bit accesses.
 // Same arithmetic as the general kernel above.
-template <typename T>
-struct RowPair {  // two rows of two values
-  T v[4];
-};
-// streaming (non-temporal) access to two rows at once, aligned to one row only
-template <typename T>
-__device__ __forceinline__ RowPair<T> load_rows2_nt(const T* base, int64_t row) {
-  typedef T V4 __attribute__((ext_vector_type(4), aligned(2 * sizeof(T))));
-  const V4 v = __builtin_nontemporal_load(reinterpret_cast<const V4*>(base + 2 * row));
-  RowPair<T> r;
-  r.v[0] = v.x; r.v[1] = v.y; r.v[2] = v.z; r.v[3] = v.w;
-  return r;
-}
-template <typename T>
-__device__ __forceinline__ void store_rows2_nt(T* base, int64_t row, const RowPair<T>& r) {
-  typedef T V4 __attribute__((ext_vector_type(4), aligned(2 * sizeof(T))));
-  const V4 v = {r.v[0], r.v[1], r.v[2], r.v[3]};
-  __builtin_nontemporal_store(v, reinterpret_cast<V4*>(base + 2 * row));
-}
 template <typename T, bool BWD>
 __device__ __forceinline__ void s1_circle_row(T m0, T m1, T k, T n0, T n1, T g0, T g1, T* o0, T* o1, T* dk) {
   const T y0 = m0 * k + n0, y1 = m1 * k + n1;
@@ -680,7 +661,8 @@ __device__ __forceinline__ void s1_circle_row(T m0, T m1, T k, T n0, T n1, T g0,
     *dk = d;
   }
 }
-template <typename T, bool BWD>
+// KP: kappa / d kappa of a pair are one aligned 64-bit unit each (even row offset, arrays aligned to two elements)
+template <typename T, bool BWD, bool KP>
 __global__ __launch_bounds__(256) void s1_projnormal2_kernel(const T* __restrict__ mean, const T* __restrict__ kappa,
                                                              const T* __restrict__ noise, const T* __restrict__ gz,
                                                              T* __restrict__ z, T* __restrict__ dmean,
@@ -704,7 +686,13 @@ __global__ __launch_bounds__(256) void s1_projnormal2_kernel(const T* __restrict
     if (va && vb) {
       // every array is touched once: non-temporal accesses
       const RowPair<T> mu = load_rows2_nt<T>(mean, ia);
-      const T ka_ = __builtin_nontemporal_load(kappa + ia), kb_ = __builtin_nontemporal_load(kappa + ib);
+      T ka_, kb_;
+      if (KP) {
+        const Pair<T> k2 = load_pair_nt<T>(kappa, ia >> 1);
+        ka_ = k2.a; kb_ = k2.b;
+      } else {
+        ka_ = __builtin_nontemporal_load(kappa + ia); kb_ = __builtin_nontemporal_load(kappa + ib);
+      }
       if (noise) {
         const RowPair<T> e = load_rows2_nt<T>(noise, ia);
         nz[0] = e.v[0]; nz[1] = e.v[1]; nz[2] = e.v[2]; nz[3] = e.v[3];
@@ -717,8 +705,12 @@ __global__ __launch_bounds__(256) void s1_projnormal2_kernel(const T* __restrict
       s1_circle_row<T, BWD>(mu.v[2], mu.v[3], kb_, nz[2], nz[3], g.v[2], g.v[3], &r.v[2], &r.v[3], &dkb);
       store_rows2_nt<T>(o, ia, r);
       if (BWD) {
-        __builtin_nontemporal_store(dka, dkappa + ia);
-        __builtin_nontemporal_store(dkb, dkappa + ib);
+        if (KP) {
+          store_pair_nt<T>(dkappa, ia >> 1, dka, dkb);
+        } else {
+          __builtin_nontemporal_store(dka, dkappa + ia);
+          __builtin_nontemporal_store(dkb, dkappa + ib);
+        }
       }
     } else {
       const int64_t i = va ? ia : ib;  // the call's first row (odd global index) or its last one (even)
@@ -753,8 +745,13 @@ extern "C" int vmf_s1_projnormal_fwd(const void* mean, const void* kappa, const 
   // 2048-workgroup grid-stride walk; forward unchanged)
   int grid = vmf_grid_for(dim == 2 ? n / 2 + 1 : n, 256, dim == 2 ? (1 << 22) : 2048);
   VMF_DISPATCH_DTYPE(dtype, {
-    if (dim == 2 && pair_aligned<T>(mean) && pair_aligned<T>(z) && pair_aligned<T>(noise))
-      hipLaunchKernelGGL((s1_projnormal2_kernel<T, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+    if (dim == 2 && pair_aligned<T>(mean) && pair_aligned<T>(z) && pair_aligned<T>(noise) && (row0 & 1u) == 0 &&
+        pair_aligned<T>(kappa))
+      hipLaunchKernelGGL((s1_projnormal2_kernel<T, false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                         (const T*)mean, (const T*)kappa, (const T*)noise, (const T*)nullptr, (T*)z, (T*)nullptr,
+                         (T*)nullptr, n, row0, key);
+    else if (dim == 2 && pair_aligned<T>(mean) && pair_aligned<T>(z) && pair_aligned<T>(noise))
+      hipLaunchKernelGGL((s1_projnormal2_kernel<T, false, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                          (const T*)mean, (const T*)kappa, (const T*)noise, (const T*)nullptr, (T*)z, (T*)nullptr,
                          (T*)nullptr, n, row0, key);
     else
@@ -777,8 +774,13 @@ extern "C" int vmf_s1_projnormal_bwd(const void* mean, const void* kappa, const 
   // 2048-workgroup grid-stride walk; forward unchanged)
   int grid = vmf_grid_for(dim == 2 ? n / 2 + 1 : n, 256, dim == 2 ? (1 << 22) : 2048);
   VMF_DISPATCH_DTYPE(dtype, {
-    if (dim == 2 && pair_aligned<T>(mean) && pair_aligned<T>(gz) && pair_aligned<T>(dmean) && pair_aligned<T>(noise))
-      hipLaunchKernelGGL((s1_projnormal2_kernel<T, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+    if (dim == 2 && pair_aligned<T>(mean) && pair_aligned<T>(gz) && pair_aligned<T>(dmean) && pair_aligned<T>(noise) &&
+        (row0 & 1u) == 0 && pair_aligned<T>(kappa) && pair_aligned<T>(dkappa))
+      hipLaunchKernelGGL((s1_projnormal2_kernel<T, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                         (const T*)mean, (const T*)kappa, (const T*)noise, (const T*)gz, (T*)nullptr, (T*)dmean,
+                         (T*)dkappa, n, row0, key);
+    else if (dim == 2 && pair_aligned<T>(mean) && pair_aligned<T>(gz) && pair_aligned<T>(dmean) && pair_aligned<T>(noise))
+      hipLaunchKernelGGL((s1_projnormal2_kernel<T, true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                          (const T*)mean, (const T*)kappa, (const T*)noise, (const T*)gz, (T*)nullptr, (T*)dmean,
                          (T*)dkappa, n, row0, key);
     else

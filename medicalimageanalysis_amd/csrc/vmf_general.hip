@@ -1177,6 +1177,25 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
     const int64_t row = valid ? r : 0;
     const T* mrow = p.mu + row * p.mu_stride;
     const T* grow_ = p.gz + row * (int64_t)m;
+    if (LPR == 1 && m == 2 && p.gauss == nullptr) {
+      // the circle, one row per lane: the tangent is the sign bit of the row's first call; the arithmetic is the function
+      // vmf_circle_bwd_kernel uses
+      if (valid) {
+        const uint64_t grow = p.row0 + (uint64_t)row;
+        const U4 r0 = philox4x32_10(grow >> 1, 0u, key);
+        const bool neg = ((((grow & 1u) != 0u) ? r0.z : r0.x) & 1u) != 0u;
+        T ksig, o0, o1, dk;
+        const T kap = kappa_of<T>(p.kappa[row * p.kappa_stride], p.softplus != 0, &ksig);
+        const T w = p.w_in[row];
+        const T omw = p.omw_in ? p.omw_in[row] : (T)1 - w;
+        circle_bwd_row<T>(mrow[0], mrow[1], grow_[0], grow_[1], neg, w, omw, kap, p.normalize != 0, &o0, &o1, &dk);
+        p.dmu[row * 2] = o0;
+        p.dmu[row * 2 + 1] = o1;
+        if (p.gkappa) dk += p.gkappa[row];
+        p.dkappa[row] = dk * ksig;
+      }
+      continue;
+    }
     T mu[P][4], g[P][4], G[P][4];
     T gg = 0, dd = 0, gm = 0, Gd = 0, Gg = 0;
 #pragma unroll
@@ -1184,14 +1203,7 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
       const int chunk = j * LPR + sub;
       load4<T, VEC, VMF_BWD_STREAM>(mrow, 4 * chunk, m, mu[j]);
       load4<T, VEC, VMF_BWD_STREAM>(grow_, 4 * chunk, m, G[j]);
-      if (LPR == 1 && m == 2 && p.gauss == nullptr) {  // circle: the tangent is the sign bit of the row's first call
-        const uint64_t grow = p.row0 + (uint64_t)row;
-        const U4 r0 = philox4x32_10(grow >> 1, 0u, key);
-        g[j][0] = g[j][2] = g[j][3] = (T)0;
-        g[j][1] = (((grow & 1u) ? r0.z : r0.x) & 1u) ? (T)-1 : (T)1;
-      } else {
-        noise4<T, VEC>(p.gauss ? p.gauss + row * (int64_t)m : nullptr, p.row0 + (uint64_t)row, chunk, m, key, g[j]);
-      }
+      noise4<T, VEC>(p.gauss ? p.gauss + row * (int64_t)m : nullptr, p.row0 + (uint64_t)row, chunk, m, key, g[j]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bool first = (chunk == 0 && i == 0);
@@ -1279,6 +1291,72 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
         if (p.gkappa) dk += p.gkappa[row];
         p.dkappa[row] = dk * ksig;
       }
+    }
+  }
+}
+
+// Backward of the circle (m = 2, dense rows, regenerated sign): a thread owns the GLOBAL pair of rows (2p, 2p+1) --
+// 128-bit accesses to mu / grad z / d mu, and the ONE Philox call whose words hold both rows' tangent signs (one call
+// per row, for one bit of it, was a third of the lane-per-row kernel's instructions).  A call whose first or last row
+// has no partner (odd row offset, odd count) handles that row alone with 64-bit accesses.
+// KP: the per-row arrays (kappa, w, 1 - w, d kappa, grad kappa) of a pair are one aligned 64-bit unit each (even row
+// offset, arrays aligned to two elements): one access per pair instead of two half-used ones.
+template <typename T, bool KP>
+__global__ __launch_bounds__(256) void vmf_circle_bwd_kernel(GenParams<T> p) {
+  const PhiloxKey key = philox_resolve(p.ka);
+  const uint64_t p0 = p.row0 >> 1;
+  const int64_t npairs = (int64_t)(((p.row0 + (uint64_t)p.n + 1u) >> 1) - p0);  // global pairs the call touches
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bool norm = p.normalize != 0, sp = p.softplus != 0;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npairs; t += stride) {
+    const uint64_t P = p0 + (uint64_t)t;
+    const int64_t ia = (int64_t)(2 * P - p.row0), ib = ia + 1;  // local indices of the pair's rows (ia may be -1)
+    const bool va = ia >= 0, vb = ib < p.n;
+    const U4 r = philox4x32_10(P, 0u, key);
+    const bool nega = (r.x & 1u) != 0u, negb = (r.z & 1u) != 0u;
+    if (va && vb) {
+      const RowPair<T> mu = load_rows2_nt<T>(p.mu, ia);
+      const RowPair<T> G = load_rows2_nt<T>(p.gz, ia);
+      T ra, rb, wa, wb, oa, ob;
+      if (KP) {
+        const Pair<T> k2 = load_pair_nt<T>(p.kappa, ia >> 1), w2 = load_pair_nt<T>(p.w_in, ia >> 1);
+        ra = k2.a; rb = k2.b; wa = w2.a; wb = w2.b;
+        oa = (T)1 - wa; ob = (T)1 - wb;
+        if (p.omw_in) {
+          const Pair<T> o2 = load_pair_nt<T>(p.omw_in, ia >> 1);
+          oa = o2.a; ob = o2.b;
+        }
+      } else {
+        ra = __builtin_nontemporal_load(p.kappa + ia); rb = __builtin_nontemporal_load(p.kappa + ib);
+        wa = __builtin_nontemporal_load(p.w_in + ia); wb = __builtin_nontemporal_load(p.w_in + ib);
+        oa = p.omw_in ? __builtin_nontemporal_load(p.omw_in + ia) : (T)1 - wa;
+        ob = p.omw_in ? __builtin_nontemporal_load(p.omw_in + ib) : (T)1 - wb;
+      }
+      T sa, sb, dka, dkb;
+      const T ka_ = kappa_of<T>(ra, sp, &sa), kb_ = kappa_of<T>(rb, sp, &sb);
+      RowPair<T> o;
+      circle_bwd_row<T>(mu.v[0], mu.v[1], G.v[0], G.v[1], nega, wa, oa, ka_, norm, &o.v[0], &o.v[1], &dka);
+      circle_bwd_row<T>(mu.v[2], mu.v[3], G.v[2], G.v[3], negb, wb, ob, kb_, norm, &o.v[2], &o.v[3], &dkb);
+      store_rows2_nt<T>(p.dmu, ia, o);
+      if (p.gkappa) { dka += p.gkappa[ia]; dkb += p.gkappa[ib]; }
+      if (KP) {
+        store_pair_nt<T>(p.dkappa, ia >> 1, dka * sa, dkb * sb);
+      } else {
+        __builtin_nontemporal_store(dka * sa, p.dkappa + ia);
+        __builtin_nontemporal_store(dkb * sb, p.dkappa + ib);
+      }
+    } else {
+      const int64_t i = va ? ia : ib;  // the call's first row (odd global index) or its last one (even)
+      const Pair<T> mu = load_pair_nt<T>(p.mu, i);
+      const Pair<T> G = load_pair_nt<T>(p.gz, i);
+      T sg, o0, o1, dk;
+      const T kap = kappa_of<T>(p.kappa[i], sp, &sg);
+      const T w = p.w_in[i];
+      const T omw = p.omw_in ? p.omw_in[i] : (T)1 - w;
+      circle_bwd_row<T>(mu.a, mu.b, G.a, G.b, va ? nega : negb, w, omw, kap, norm, &o0, &o1, &dk);
+      store_pair_nt<T>(p.dmu, i, o0, o1);
+      if (p.gkappa) dk += p.gkappa[i];
+      p.dkappa[i] = dk * sg;
     }
   }
 }
@@ -1680,6 +1758,16 @@ static int rsample_bwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   int64_t gb = (waves + WAVES - 1) / WAVES;
   VMF_REQUIRE(gb <= 0x7fffffff, VMF_ERR_UNSUPPORTED, "n=%lld rows need more than 2^31 workgroups", (long long)n);
   const int grid = (int)(gb < 1 ? 1 : gb);
+  // dense circles with the regenerated sign: a thread per global pair of rows
+  if (m == 2 && !gauss && mu_stride == 2 && kappa_stride == 1 && ((uintptr_t)mu % (2 * sizeof(T))) == 0 &&
+      ((uintptr_t)gz % (2 * sizeof(T))) == 0 && ((uintptr_t)dmu % (2 * sizeof(T))) == 0) {
+    const auto al2 = [](const void* q) { return ((uintptr_t)q % (2 * sizeof(T))) == 0; };
+    const bool kp = (row0 & 1u) == 0 && al2(kappa) && al2(w) && al2(omw) && al2(dkappa);
+    const dim3 cgrid(vmf_grid_for(n / 2 + 1, 256, 1 << 22));
+    if (kp) hipLaunchKernelGGL((vmf_circle_bwd_kernel<T, true>), cgrid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((vmf_circle_bwd_kernel<T, false>), cgrid, dim3(256), 0, s, p);
+    return VMF_OK;
+  }
   if constexpr (sizeof(T) == 4) {
     // narrow rows of a width that is not a multiple of four, regenerated noise: one lane per row whatever the layout
     if (rowlane_bwd_ok(m) && !gauss) {

@@ -700,6 +700,50 @@ __device__ __forceinline__ void circle_compose(T mu0, T mu1, T w, T fs, bool nor
   *mz = vfma(w, m0, fm) - coef * vfma(m0, d0, -tail);
 }
 
+// Backward of one circle row: (d0, d1) = J^T G with respect to mu (raw mu when `normalize`) and *dk = dz/dkappa . G
+// through w(kappa).  mu = (m0, m1), G = grad z, neg = the row's tangent sign, (w, omw = 1 - w) as the forward left them.
+// The general backward kernel specialised to m = 2 (tangent noise g = (0, +-1), |g| = 1); both kernels that take
+// circle rows call it, so a row's gradient does not depend on where a shard's rows start.
+template <typename T>
+__device__ __forceinline__ void circle_bwd_row(T mu0, T mu1, T G0, T G1, bool neg, T w, T omw, T kap, bool normalize,
+                                               T* d0_out, T* d1_out, T* dk) {
+#pragma clang fp contract(off)
+  T inv = (T)1;
+  if (normalize) inv = F<T>::rsqrt(vfma(mu1, mu1, mu0 * mu0));
+  const T m0 = mu0 * inv, mh = mu1 * inv;
+  const T sg = neg ? (T)-1 : (T)1;
+  const T gm = sg * mh;                        // <g, mu_hat>
+  const T d0 = (T)1 - m0;
+  const T Gd = vfma(G0, d0, -(G1 * mh));       // <G, e1 - mu_hat>
+  const T dd = vfma(d0, d0, mh * mh);          // |e1 - mu_hat|^2
+  T c2 = omw * ((T)1 + w);
+  const bool inside = c2 >= (T)1e-10;
+  c2 = inside ? c2 : (T)1e-10;
+  const T sq = F<T>::sqrt(c2);                 // f = sqrt(1 - w^2) / |g|
+  const T zd = vfma(w, d0, -(sq * gm));        // <z', d>
+  const T inv_dd = dd > (T)1e-30 ? F<T>::rcp(dd) : (T)0;
+  const T t = ((T)2 * zd) * (Gd * inv_dd);     // 2 zd Gd / |d|^2
+  T o0 = (T)2 * (vfma(w, Gd, vfma(zd, G0, -(t * d0)))) * inv_dd;
+  T o1 = (T)2 * (vfma(sq * sg, Gd, vfma(zd, G1, t * mh))) * inv_dd;
+  if (normalize) {  // d mu = (d mu_hat - mu_hat <mu_hat, d mu_hat>) / ||mu||
+    const T dot = vfma(o0, m0, o1 * mh);
+    o0 = vfma(-m0, dot, o0) * inv;
+    o1 = vfma(-mh, dot, o1) * inv;
+  }
+  *d0_out = o0;
+  *d1_out = o1;
+  const T g2 = ((T)2 * Gd) * inv_dd;
+  const T Gp0 = vfma(-g2, d0, G0);
+  const T S = vfma(g2, gm, G1 * sg);
+  const T dw = Gp0 + (inside ? S * (-w * F<T>::rcp(sq)) : (T)0);
+  const T c = F<T>::sqrt(vfma((T)4 * kap, kap, (T)1));
+  const T b = F<T>::rcp(vfma((T)2, kap, c));
+  const T e = omw * F<T>::rcp(((T)1 + b) - w * ((T)1 - b));
+  const T den = (T)1 - ((T)1 - b) * e;
+  const T dw_db = ((T)-2 * e) * ((T)1 - e) * F<T>::rcp(den * den);
+  *dk = dw * dw_db * (((T)-2 * b) * F<T>::rcp(c));
+}
+
 // b(kappa) alone (what the counter-based path needs)
 template <typename T>
 __device__ __forceinline__ T wood_b(T kappa, int m) {

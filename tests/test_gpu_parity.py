@@ -1267,6 +1267,55 @@ def test_circle_pair_kernel_and_row_kernel_give_the_same_bits(opts, max_prop):
         assert torch.equal(z1, got_pair[0][1:])
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("opts", [False, True])
+def test_circle_backward_pair_kernel_and_row_kernel_give_the_same_bits(opts, dt):
+    """m = 2 backward with the regenerated sign: dense rows aligned to a row take the thread-per-pair kernel, any other
+    layout the lane-per-row one.  Same rows through both (aligned; from a view that starts one element into its buffer),
+    and a shard that starts on an odd global row, must give the same gradient bits."""
+    lib, sp = _lib.lib(), _lib.stream_ptr(DEV)
+    g = torch.Generator(device=DEV).manual_seed(61)
+    n = 3 * 256 * 2 + 51
+    es = 4 if dt == torch.float32 else 8
+    mu = torch.randn(n, 2, device=DEV, generator=g, dtype=dt)
+    if not opts:
+        mu = torch.nn.functional.normalize(mu, dim=-1)
+    kap = (torch.randn(n, device=DEV, generator=g, dtype=dt) * 3) if opts else torch.exp(torch.rand(n, device=DEV, generator=g, dtype=dt) * 7)
+    flags = (_lib.FLAG_NORMALIZE_MU | _lib.FLAG_SOFTPLUS_KAPPA) if opts else 0
+    row0, seed, off = 1 << 33, 21, 5
+    z, w, omw = torch.empty_like(mu), torch.empty_like(kap), torch.empty_like(kap)
+    _lib.check(lib.vmf_rsample_fwd(_lib.ptr(mu), 2, _lib.ptr(kap), 1, _lib.ptr(z), _lib.ptr(w), _lib.ptr(omw), None, None,
+                                   None, n, 2, None, None, 0, None, 64, row0, seed, off, None, flags, _lib.dtype_code(mu), sp),
+               "vmf_rsample_fwd")
+    gz = torch.randn(n, 2, device=DEV, generator=g, dtype=dt)
+    gk = torch.randn(n, device=DEV, generator=g, dtype=dt) if opts else None
+
+    def run(mu_t, gz_t, dmu_t, lo=0):
+        cnt = n - lo
+        dk = torch.full((cnt,), float("nan"), device=DEV, dtype=dt)
+        _lib.check(lib.vmf_rsample_bwd(_lib.ptr(mu_t), 2, _lib.ptr(kap[lo:]), 1, _lib.ptr(w[lo:]), _lib.ptr(omw[lo:]),
+                                       _lib.ptr(gz_t), None, _lib.ptr(gk[lo:]) if opts else None, _lib.ptr(dmu_t), _lib.ptr(dk),
+                                       cnt, 2, row0 + lo, seed, off, None, flags, _lib.dtype_code(mu), sp), "vmf_rsample_bwd")
+        return dmu_t.clone(), dk
+
+    d_al = torch.full((n, 2), float("nan"), device=DEV, dtype=dt)
+    assert mu.data_ptr() % (2 * es) == 0 and gz.data_ptr() % (2 * es) == 0
+    dmu_pair, dk_pair = run(mu, gz, d_al)
+    bufs = [torch.full((2 * n + 1,), float("nan"), device=DEV, dtype=dt) for _ in range(3)]
+    mu_o, gz_o, d_o = (b[1:].view(n, 2) for b in bufs)
+    mu_o.copy_(mu)
+    gz_o.copy_(gz)
+    assert mu_o.data_ptr() % (2 * es) == es
+    dmu_row, dk_row = run(mu_o, gz_o, d_o)
+    assert bool(torch.isfinite(dmu_pair).all()) and bool(torch.isfinite(dk_pair).all())
+    assert torch.equal(dmu_pair, dmu_row) and torch.equal(dk_pair, dk_row)
+    assert float(bufs[2][0]) != float(bufs[2][0])   # the element in front of the view is untouched
+    # a shard that starts on an odd global row: its first row has no partner in the call
+    d1 = torch.full((n - 1, 2), float("nan"), device=DEV, dtype=dt)
+    dmu_odd, dk_odd = run(mu[1:], gz[1:], d1, lo=1)
+    assert torch.equal(dmu_odd, dmu_pair[1:]) and torch.equal(dk_odd, dk_pair[1:])
+
+
 def test_circle_counter_noise_backward_regenerates_the_forward_sign():
     """m = 2 with in-kernel noise: two proposals per Philox call and a one-bit tangent.  The backward pass
     regenerates that bit; check it against autograd through the forward restated in torch with the accepted proposal
