@@ -245,7 +245,10 @@ VMF_HD float kl_m2_value_f32(float a);  // (defined below, next to its coefficie
 // exponentials up to 10, exp(k - ln 2) beyond (sinh = cosh to 2e-9 there)
 VMF_HD void fast_sinh_cosh(float k, float* sh, float* ch) {
   if (k > 10.0f) {
-    *sh = *ch = fast_exp(k - 0.69314718055994530942f);
+    // sinhf is finite up to the float 89.415985 (0x42b2d4fc) and overflows from the next one on; k - ln 2 and its
+    // product with log2 e are rounded, so the exponential alone would put that last float on the wrong side
+    const float E = fast_exp(k - 0.69314718055994530942f);
+    *sh = *ch = k <= 89.415985f ? ::fminf(E, 3.4028234663852886e38f) : INFINITY;
     return;
   }
   const float e = fast_exp(k), ei = fast_rcp(e);

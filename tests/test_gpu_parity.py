@@ -1837,6 +1837,18 @@ def test_host_counter_refuses_capture():
     assert gen.ticket(DEV)[2].item() == -1 and gen.get_state()["offset"] == 0
 
 
+def test_kl_overflow_points_agree_with_the_checker_float_for_float():
+    """every float32 in the intervals where e^k and sinh k leave the float range (and 4000 doubles either side of the
+    double-precision points), all six variants, every position inside a quad: NaN / inf exactly where the CPU checker
+    has them.  (sinhf is finite at 89.415985 and infinite at the next float; a rounded k - ln 2 put that float on the
+    wrong side once.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("scan_kl_thresholds", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "scan_kl_thresholds.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.scan() == 0
+
+
 def test_philox_ticket_is_one_launch_snapshot_and_advance():
     lib, sp = _lib.lib(), _lib.stream_ptr(DEV)
     ctr = torch.tensor([41], dtype=torch.int64, device=DEV)
