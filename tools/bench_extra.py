@@ -11,6 +11,8 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+from _timing import timeit as _timeit  # noqa: E402
+
 from medicalimageanalysis_amd import _lib, kl as klmod, rng  # noqa: E402
 from medicalimageanalysis_amd.sampler.ive import ive  # noqa: E402
 from medicalimageanalysis_amd.sampler.von_mises_fisher import VonMisesFisher, VonMisesFisher3D  # noqa: E402
@@ -18,17 +20,8 @@ from medicalimageanalysis_amd.sampler.von_mises_fisher import VonMisesFisher, Vo
 DEV = torch.device("cuda:0")
 
 
-def timeit(fn, reps=10, warm=10):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for a, b in ev:
-        a.record()
-        fn()
-        b.record()
-    torch.cuda.synchronize()
-    return float(np.median([a.elapsed_time(b) for a, b in ev]))
+def timeit(fn, reps=30, warm=None):
+    return _timeit(fn, reps=reps, warm_calls=warm)
 
 
 def row(name, ms, nbytes, units, unit_name):
@@ -184,8 +177,8 @@ def main():
         opt.step()
 
     os.environ["VMF_RNG"] = "torch"
-    ms_a = timeit(step_ours, reps=30, warm=5)
-    ms_b = timeit(step_torch, reps=30, warm=5)
+    ms_a = timeit(step_ours, reps=30)
+    ms_b = timeit(step_torch, reps=30)
     print(f"| SphericalVAE train step B=128 (z 128x128x3): this package | {ms_a:.3f} | - | {1e3 / ms_a:.0f} steps/s |")
     print(f"| same step with the sampler/KL as torch ops (reference formulas) | {ms_b:.3f} | - | {1e3 / ms_b:.0f} steps/s |")
 
@@ -201,7 +194,7 @@ def main():
     for mode in ("torch", "philox"):
         os.environ["VMF_RNG"] = mode
         gstep = GraphedTrainStep(model_g, opt_g, loss_fn, [x], tune_gemms=True)
-        ms_g = timeit(lambda: gstep(x), reps=30, warm=5)
+        ms_g = timeit(lambda: gstep(x), reps=30)
         print(f"| same step as one HIP graph, fused Adam, tuned GEMMs ({mode} noise) | {ms_g:.3f} | - | {1e3 / ms_g:.0f} steps/s |")
     os.environ["VMF_RNG"] = "torch"
 
@@ -218,10 +211,10 @@ def main():
         opt9.zero_grad(set_to_none=True)
         loss.backward()
         opt9.step()
-    ms_9 = timeit(step9, reps=30, warm=5)
+    ms_9 = timeit(step9, reps=30)
     print(f"| HypersphericalVAE train step B=128, latent S^9 (z 128x10) | {ms_9:.3f} | - | {1e3 / ms_9:.0f} steps/s |")
     g9 = GraphedTrainStep(model9, opt9, loss_fn, [x], tune_gemms=True)
-    ms_9g = timeit(lambda: g9(x), reps=30, warm=5)
+    ms_9g = timeit(lambda: g9(x), reps=30)
     print(f"| same S^9 step as one HIP graph, fused Adam, tuned GEMMs | {ms_9g:.3f} | - | {1e3 / ms_9g:.0f} steps/s |")
 
     # --- consumers: fused ELBO on the (128, 128, 784) decoder output, torus embedding, latent losses
@@ -263,15 +256,15 @@ def main():
         rc = lib.vmf_rsample_fwd(_lib.ptr(mu), 2, _lib.ptr(kap), 1, _lib.ptr(z), None, None, None, None, None, n, 2, None, None,
                                  0, None, 64, 0, 1, 0, None, 0, _lib.VMF_F32, sp)
         assert rc == 0
-    ms = timeit(f5, reps=10, warm=10)
+    ms = timeit(f5, reps=10)
     row("T^16: vMF m=2, 2^23 x 16 circles fp32", ms, n * 20, n, "circle draws")
 
     def f6():
         rc = lib.vmf_s1_projnormal_fwd(_lib.ptr(mu), _lib.ptr(kap), None, _lib.ptr(z), n, 2, 0, 1, 0, None, _lib.VMF_F32, sp)
         assert rc == 0
-    ms = timeit(f6, reps=10, warm=10)
+    ms = timeit(f6, reps=10)
     row("S^1 projected normal 2^27 rows fp32", ms, n * 20, n, "rows")
-    ms = timeit(lambda: klmod.kl_sum(kap, "s1"), reps=10, warm=10)
+    ms = timeit(lambda: klmod.kl_sum(kap, "s1"), reps=10)
     row("KL sum (S^1, I1/I0) 2^27 fp32", ms, n * 4, n, "elems")
     del mu, kap, z
     torch.cuda.empty_cache()
@@ -280,7 +273,7 @@ def main():
     n = 1 << 24
     x = torch.exp(torch.rand(n, device=DEV, generator=g, dtype=torch.float64) * np.log(1e5))
     for v in (0.5, 31.0, 255.0):
-        ms = timeit(lambda: ive(v, x), reps=10, warm=10)
+        ms = timeit(lambda: ive(v, x), reps=10)
         row(f"ive({v}, z) n=2^24 fp64 forward", ms, n * 16, n, "evals")
     xr = x.clone().requires_grad_()
     y = ive(31.0, xr)
@@ -288,7 +281,7 @@ def main():
     def fbw():
         xr.grad = None
         y.backward(torch.ones_like(y), retain_graph=True)
-    ms = timeit(fbw, reps=10, warm=10)
+    ms = timeit(fbw, reps=10)
     row("ive(31, z) n=2^24 fp64 backward", ms, n * 24, n, "evals")
 
 

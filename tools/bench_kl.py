@@ -41,7 +41,7 @@ for v in args.only.split(","):
     def f():
         rc = lib.vmf_kl_fwd(_lib.ptr(data), None, _lib.ptr(acc), _lib.ptr(ws), 1.0, n, klmod.VARIANTS[v], _lib.VMF_F32, sp)
         assert rc == 0
-    ms = timeit(f, reps=args.reps, warm=min(10, args.reps))
+    ms = timeit(f, reps=args.reps, warm=(args.reps if args.reps < 10 else None))
     print(f"| KL sum {v} fp32 2^27, kappa log-uniform {rng_} | {ms:.3f} | {n * 4 / ms / 1e6:.0f} | {n * 4 / ms / 8e7:.1f} % |",
           flush=True)
 # fused ELBO through the C ABI: x (B, D) against x_hat (B, B, D), the reference's broadcast (model/spherical_vae.py:133-138)
@@ -63,10 +63,10 @@ for B in (128, 1024):
         rc = lib.vmf_elbo_bwd(_lib.ptr(x), _lib.ptr(xh), _lib.ptr(kp), _lib.ptr(one1), _lib.ptr(dxh), _lib.ptr(dkp),
                               1.0 / xh.numel(), 1.0 / B, x.numel(), xh.numel(), B, klmod.VARIANTS["spherical"], _lib.VMF_F32, sp)
         assert rc == 0
-    ms = timeit(ef, reps=args.reps, warm=min(10, args.reps))
+    ms = timeit(ef, reps=args.reps, warm=(args.reps if args.reps < 10 else None))
     print(f"| fused ELBO forward, x_hat ({B},{B},{D}) fp32 | {ms:.4f} | {xh.numel() * 4 / ms / 1e6:.0f} | "
           f"{xh.numel() * 4 / ms / 8e7:.1f} % |", flush=True)
-    ms = timeit(eb, reps=args.reps, warm=min(10, args.reps))
+    ms = timeit(eb, reps=args.reps, warm=(args.reps if args.reps < 10 else None))
     print(f"| fused ELBO backward, x_hat ({B},{B},{D}) fp32 | {ms:.4f} | {xh.numel() * 8 / ms / 1e6:.0f} | "
           f"{xh.numel() * 8 / ms / 8e7:.1f} % |", flush=True)
     del x, xh, dxh
@@ -79,9 +79,9 @@ if not args.no_ive:
         rc = lib.vmf_kl_bwd(_lib.ptr(kg), _lib.ptr(one), 0, 1.0 / kg.numel(), _lib.ptr(dk), kg.numel(),
                             klmod.VARIANTS["spherical"], _lib.VMF_F32, sp)
         assert rc == 0
-    ms = timeit(bw, reps=10, warm=10)
+    ms = timeit(bw, reps=10)
     print(f"| KL mean backward spherical fp32 2^24 | {ms:.3f} | {(1 << 24) * 8 / ms / 1e6:.0f} | |")
     x = kap[: 1 << 24].double()
     for v in (0, 1, 0.5, 2.0):
-        ms = timeit(lambda: ive(v, x), reps=10, warm=10)
+        ms = timeit(lambda: ive(v, x), reps=10)
         print(f"| ive({v}) fp64 2^24 | {ms:.3f} | {(1 << 24) * 16 / ms / 1e6:.0f} | |")

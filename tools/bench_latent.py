@@ -10,22 +10,15 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+from _timing import timeit as _timeit  # noqa: E402
+
 from medicalimageanalysis_amd import _lib  # noqa: E402
 
 DEV = torch.device("cuda:0")
 
 
-def timeit(fn, reps=20, warm=10):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for a, b in ev:
-        a.record()
-        fn()
-        b.record()
-    torch.cuda.synchronize()
-    return float(np.median([a.elapsed_time(b) for a, b in ev]))
+def timeit(fn, reps=30, warm=None):
+    return _timeit(fn, reps=reps)
 
 
 def main():

@@ -13,6 +13,8 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+from _timing import timeit as _timeit  # noqa: E402
+
 from medicalimageanalysis_amd import _lib  # noqa: E402
 from medicalimageanalysis_amd.sampler.von_mises_fisher import vmf3_broadcast_plan  # noqa: E402
 
@@ -23,18 +25,7 @@ REPS = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 
 
 
 def timeit(fn, reps=None, warm=None):
-    reps = reps or REPS
-    warm = min(10, reps) if warm is None else warm
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for a, b in ev:
-        a.record()
-        fn()
-        b.record()
-    torch.cuda.synchronize()
-    return float(np.median([a.elapsed_time(b) for a, b in ev]))
+    return _timeit(fn, reps=reps or REPS, warm_calls=warm)
 
 
 def row(name, ms, nbytes):
