@@ -350,6 +350,10 @@ __global__ __launch_bounds__(256) void latent_loss_bwd_kernel(const T* __restric
 // functions, same bits per row.
 constexpr int LL_BLOCK = 512;
 constexpr int LL_TILE = 256;
+// four consecutive floats with the alignment of one (a lane's label rows start wherever row mod n_labels puts them)
+struct __attribute__((packed, aligned(4))) LlQuad {
+  float v[4];
+};
 template <bool BWD>
 __global__ __launch_bounds__(LL_BLOCK) void latent_loss_tile_kernel(const float* __restrict__ z,
                                                                     const float* __restrict__ labels,
@@ -372,25 +376,55 @@ __global__ __launch_bounds__(LL_BLOCK) void latent_loss_tile_kernel(const float*
   // label row of z row i is i mod n_labels: one division per lane, then conditional subtractions
   const int64_t lstep = (wstride * LL_TILE) % n_labels;
   int64_t li = (w0 * LL_TILE + 4 * lane) % n_labels;
+  // the NEXT tile's three accesses are sent for as soon as the current tile sits in the slab: a wave walks eight or
+  // more tiles, and without this every one of them waited out a full HBM round trip before its arithmetic started
+  u32x4 nx[3];
+  if (w0 < ntiles) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(z + 3 * LL_TILE * w0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) nx[k] = __builtin_nontemporal_load(src + lane + 64 * k);
+  }
   for (int64_t t = w0; t < ntiles; t += wstride) {
-    const u32x4* src = reinterpret_cast<const u32x4*>(z + 3 * LL_TILE * t);
     u32x4 u[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) u[k] = __builtin_nontemporal_load(src + lane + 64 * k);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) slab[lane + 64 * k] = u[k];
+    for (int k = 0; k < 3; ++k) slab[lane + 64 * k] = nx[k];
     wave_lds_sync();
+    if (t + wstride < ntiles) {
+      const u32x4* src = reinterpret_cast<const u32x4*>(z + 3 * LL_TILE * (t + wstride));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) nx[k] = __builtin_nontemporal_load(src + lane + 64 * k);
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) u[k] = slab[3 * lane + k];
     wave_lds_sync();
     float a[12], d[12], v[4];
     __builtin_memcpy(a, u, 48);
+    // The lane's four label rows are consecutive (row -> row mod n_labels) unless the table wraps inside them: one or
+    // two 128-bit accesses fetch them.  (Row by row they were four or eight 4-byte gathers per lane and tile, 32 bytes
+    // apart from lane to lane -- the address unit's time for those was the kernel's time: S1, one column, ran at 43 us
+    // per 2^24 rows, S2 / T2, two columns, at 70.)
+    float lab[4][2];
+    if (li + 4 <= n_labels && lcols == 2) {
+      const LlQuad q0 = *reinterpret_cast<const LlQuad*>(labels + 2 * li);
+      const LlQuad q1 = *reinterpret_cast<const LlQuad*>(labels + 2 * li + 4);
+      lab[0][0] = q0.v[0]; lab[0][1] = q0.v[1]; lab[1][0] = q0.v[2]; lab[1][1] = q0.v[3];
+      lab[2][0] = q1.v[0]; lab[2][1] = q1.v[1]; lab[3][0] = q1.v[2]; lab[3][1] = q1.v[3];
+    } else if (li + 4 <= n_labels && lcols == 1) {
+      const LlQuad q0 = *reinterpret_cast<const LlQuad*>(labels + li);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int64_t l = li + j;
-      while (l >= n_labels) l -= n_labels;
-      v[j] = latent_loss_row<float, BWD>(a + 3 * j, 3, labels + l * lcols, variant, R, r, BWD ? d + 3 * j : nullptr);
+      for (int j = 0; j < 4; ++j) { lab[j][0] = q0.v[j]; lab[j][1] = 0.0f; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int64_t l = li + j;
+        while (l >= n_labels) l -= n_labels;
+        lab[j][0] = labels[l * lcols];
+        lab[j][1] = lcols > 1 ? labels[l * lcols + 1] : 0.0f;
+      }
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      v[j] = latent_loss_row<float, BWD>(a + 3 * j, 3, lab[j], variant, R, r, BWD ? d + 3 * j : nullptr);
     if (BWD) {
 #pragma unroll
       for (int c = 0; c < 12; ++c) d[c] *= g;

@@ -102,9 +102,40 @@ VMF_HD void torus_point_bwd(T ct, T cp, T sp, T R, T r, const T g[3], T gt[2], T
 // is written to dz[0..zdim) (not yet scaled by the upstream gradient / row count).
 enum { VMF_LL_S1 = VMF_LATENT_S1, VMF_LL_S2 = VMF_LATENT_S2, VMF_LL_T2 = VMF_LATENT_T2 };
 
+// Single precision takes the same quantities WITHOUT the inverse trigonometric functions: every angle the reference
+// recovers (atan2, acos) enters its loss only through cosines and sines of differences with a label angle, and
+//   1 - cos(a - b) = [(cos a - cos b)^2 + (sin a - sin b)^2] / 2,   sin(a - b) = sin a cos b - cos a sin b
+// with (cos, sin) of the recovered angle read off the row itself (x / rho, y / rho; z_3 / |z|, sqrt(1 - (z_3/|z|)^2)).
+// The half-chord form has no cancellation, so a nearly converged row (difference d) keeps the relative accuracy the
+// reference's float evaluation has (absolute error ~1e-7 in each unit vector against a chord of length d) -- and a row
+// costs two sine / cosine pairs and two reciprocal roots instead of two polynomial arctangents, an arccosine and five
+// sines / cosines.  Rows at a pole of the angle (rho or the tube radius below 1e-15 or beyond 1e15) take the
+// reference's sequence.
+VMF_HD bool ll_tame(float a) { return a > 1e-30f && a < 1e30f; }
+VMF_HD float ll_half_chord2(float c0, float s0, float c1, float s1) {
+  const float dc = c0 - c1, ds = s0 - s1;
+  return 0.5f * (dc * dc + ds * ds);
+}
+
 template <typename T, bool GRAD>
 VMF_HD T latent_loss_s1(const T* z, int zdim, T gt_phi, T* dz) {
   const T x = z[0], y = z[1];
+  if constexpr (sizeof(T) == 4) {
+    const float r2 = x * x + y * y;
+    if (ll_tame(r2)) {
+      const float ir = MT<float>::div(1.0f, MT<float>::sqrt(r2));
+      const float cp = x * ir, sp = y * ir, cg = MT<float>::cos(gt_phi), sg = MT<float>::sin(gt_phi);
+      const float om = ll_half_chord2(cp, sp, cg, sg);
+      if (GRAD) {
+        const float dphi = 2.0f * om * (sp * cg - cp * sg);
+        const float q = MT<float>::div(dphi, r2);
+        dz[0] = -y * q;
+        dz[1] = x * q;
+        for (int c = 2; c < zdim; ++c) dz[c] = 0.0f;
+      }
+      return om * om;
+    }
+  }
   T phi = wrap_2pi<T>(MT<T>::atan2(y, x));             // :116-117
   T a = phi - gt_phi;
   T d = MT<T>::cos(a);                                 // :121
@@ -127,6 +158,35 @@ VMF_HD T latent_loss_s2(const T* z, int zdim, T theta_gt, T phi_gt, T* dz) {
   const T x = z[0], y = z[1];
   const T raw = MT<T>::div(z[2], nrm);
   const T zc = raw < (T)-1 ? (T)-1 : (raw > (T)1 ? (T)1 : raw);   // :138
+  if constexpr (sizeof(T) == 4) {
+    const float r2 = x * x + y * y;
+    if (ll_tame(r2) && ll_tame(ss)) {
+      const float sth = MT<float>::sqrt((1.0f - zc) * (1.0f + zc));  // sin(theta_hat) >= 0: theta_hat lies in [0, pi]
+      const float ir = MT<float>::div(1.0f, MT<float>::sqrt(r2));
+      const float cph = x * ir, sph = y * ir;
+      const float cgt = MT<float>::cos(theta_gt), sgt = MT<float>::sin(theta_gt);
+      const float cpg = MT<float>::cos(phi_gt), spg = MT<float>::sin(phi_gt);
+      const float term1 = ll_half_chord2(cgt, sgt, zc, sth);   // 1 - cos(theta_gt - theta_hat)   :147
+      const float omc = ll_half_chord2(cpg, spg, cph, sph);    // 1 - cos(phi_gt - phi_hat)
+      const float term2 = sgt * sth * omc;                     // :148
+      const float s = term1 + term2;
+      if (GRAD) {
+        const float dl = 2.0f * s;
+        const float sin_dth = sgt * zc - cgt * sth, sin_dph = spg * cph - cpg * sph;
+        const float d_theta_hat = dl * (-sin_dth + sgt * zc * omc);
+        const float d_phi_hat = dl * (-(sgt * sth * sin_dph));
+        const float d_raw = (raw >= -1.0f && raw <= 1.0f) ? MT<float>::div(-d_theta_hat, sth) : 0.0f;
+        const float qphi = MT<float>::div(d_phi_hat, r2);
+        const float rn = MT<float>::div(d_raw, nrm);
+        const float k3 = MT<float>::div(-rn * z[2], ss);
+        for (int c = 0; c < zdim; ++c) dz[c] = k3 * z[c];
+        dz[2] += rn;
+        dz[0] -= y * qphi;
+        dz[1] += x * qphi;
+      }
+      return s * s;                                            // :149
+    }
+  }
   const T theta_hat = MT<T>::acos(zc);                 // :140
   const T phi_hat = wrap_2pi<T>(MT<T>::atan2(y, x));   // :141-142
   const T dth = theta_gt - theta_hat, dph = phi_gt - phi_hat;
@@ -157,6 +217,29 @@ VMF_HD T latent_loss_t2(const T* z, int zdim, T l_theta, T l_phi, T R, T r, T* d
   const T x = z[0], y = z[1], zc = z[2];
   const T rho = MT<T>::sqrt(x * x + y * y);            // :162
   const T s = rho - R;
+  if constexpr (sizeof(T) == 4) {
+    const float r2 = x * x + y * y, h2 = s * s + zc * zc;
+    if (ll_tame(r2) && ll_tame(h2)) {
+      const float ir = MT<float>::div(1.0f, rho), ih = MT<float>::div(1.0f, MT<float>::sqrt(h2));
+      const float cph = x * ir, sph = y * ir, cth = s * ih, sth = zc * ih;
+      const float clt = MT<float>::cos(l_theta), slt = MT<float>::sin(l_theta);
+      const float clp = MT<float>::cos(l_phi), slp = MT<float>::sin(l_phi);
+      const float q = h2 - r * r;                              // :174
+      const float val = ll_half_chord2(cth, sth, clt, slt) + ll_half_chord2(cph, sph, clp, slp) + 0.1f * (q * q);
+      if (GRAD) {
+        const float d_theta = sth * clt - cth * slt, d_phi = sph * clp - cph * slp, d_q = 0.2f * q;
+        const float qth = MT<float>::div(d_theta, h2);
+        const float d_s = -zc * qth + d_q * 2.0f * s;
+        const float d_zc = s * qth + d_q * 2.0f * zc;
+        const float qs = d_s * ir, qphi = MT<float>::div(d_phi, r2);
+        dz[0] = x * qs - y * qphi;
+        dz[1] = y * qs + x * qphi;
+        dz[2] = d_zc;
+        for (int c = 3; c < zdim; ++c) dz[c] = 0.0f;
+      }
+      return val;
+    }
+  }
   const T phi = wrap_2pi<T>(MT<T>::atan2(y, x));       // :164,168
   const T theta = wrap_2pi<T>(MT<T>::atan2(zc, s));    // :165,169
   const T a = theta - l_theta, b = phi - l_phi;
