@@ -25,7 +25,10 @@ REPS = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 
 
 
 def timeit(fn, reps=None, warm=None):
-    return _timeit(fn, reps=reps or REPS, warm_calls=warm)
+    reps = reps or REPS
+    if warm is None and reps < 10:  # profiler passes: every call is a traced dispatch
+        warm = reps
+    return _timeit(fn, reps=reps, warm_calls=warm)
 
 
 def row(name, ms, nbytes):
