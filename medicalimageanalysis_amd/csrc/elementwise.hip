@@ -673,7 +673,10 @@ __global__ __launch_bounds__(256) void s1_projnormal2_kernel(const T* __restrict
   const int64_t npairs = (int64_t)(((row0 + (uint64_t)n + 1u) >> 1) - p0);  // global pairs the call touches
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   T* const o = BWD ? dmean : z;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npairs; t += stride) {
+  // forward (12 B read, 8 B written per row -- a near 1:1 stream): blocks dealt so that an XCD works on one
+  // contiguous eighth of the rows, 0.439 -> 0.421 ms per 2^27 rows; the read-heavy backward measures 2 % slower that way
+  const int64_t b0 = BWD ? (int64_t)blockIdx.x : (int64_t)xcd_block(blockIdx.x, gridDim.x);
+  for (int64_t t = b0 * blockDim.x + threadIdx.x; t < npairs; t += stride) {
     const uint64_t P = p0 + (uint64_t)t;
     const int64_t ia = (int64_t)(2 * P - row0), ib = ia + 1;  // local indices of the pair's rows (ia may be -1)
     const bool va = ia >= 0, vb = ib < n;

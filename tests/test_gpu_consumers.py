@@ -72,6 +72,36 @@ def test_elbo_through_the_c_abi_with_parts():
     assert rc == -1 and b"multiple" in _lib.lib().vmf_last_error_string()
 
 
+@pytest.mark.parametrize("n_x,reps", [(784 * 128, 420), (100, 400003), (4096, 9001), (4100, 9001)])
+def test_elbo_backward_of_large_tensors_one_tile_per_wave(n_x, reps):
+    """from 8192 tiles of 16 KiB on, d x_hat is written by the kernel that gives every wave one contiguous tile: same
+    values as c (x_hat - x[e mod n_x]) element for element, for x longer and shorter than a tile, a ragged last tile,
+    and d kappa from the same launch"""
+    gen = torch.Generator(device=DEV).manual_seed(n_x)
+    n_hat = n_x * reps
+    assert n_hat >= 8192 * 4096
+    x = torch.randn(n_x, device=DEV, generator=gen)
+    xh = torch.randn(n_hat, device=DEV, generator=gen)
+    kap = torch.rand(777, device=DEV, generator=gen) * 40 + 1
+    go = torch.tensor([1.7], device=DEV)
+    d = torch.full((n_hat + 8,), float("nan"), device=DEV)
+    dk = torch.full((777,), float("nan"), device=DEV)
+    a_rec, a_kl = 0.3 / n_hat, 0.01 / 777
+    rc = _lib.lib().vmf_elbo_bwd(_lib.ptr(x), _lib.ptr(xh), _lib.ptr(kap), _lib.ptr(go), _lib.ptr(d), _lib.ptr(dk), a_rec,
+                                 a_kl, n_x, n_hat, 777, _lib.KL_SPHERICAL_PIECEWISE, _lib.VMF_F32, _lib.stream_ptr(DEV))
+    assert rc == 0, _lib.lib().vmf_last_error_string()
+    c = np.float32(2.0) * np.float32(a_rec) * np.float32(1.7)
+    ref = torch.tensor(c, device=DEV) * (xh.view(reps, n_x) - x)
+    assert torch.equal(d[:n_hat].view(reps, n_x), ref)
+    assert bool(torch.isnan(d[n_hat:]).all())            # nothing past the end
+    # d kappa: the grid-stride kernel's values (a call without d x_hat takes it)
+    dk2 = torch.empty_like(dk)
+    rc = _lib.lib().vmf_elbo_bwd(None, None, _lib.ptr(kap), _lib.ptr(go), None, _lib.ptr(dk2), a_rec, a_kl, n_x, n_hat, 777,
+                                 _lib.KL_SPHERICAL_PIECEWISE, _lib.VMF_F32, _lib.stream_ptr(DEV))
+    assert rc == 0
+    assert torch.equal(dk, dk2)
+
+
 @pytest.mark.parametrize("shape_x,shape_h", [((5, 7), (5, 7)), ((5, 7), (3, 5, 7)), ((1, 7), (5, 7)), ((5, 1), (5, 6)),
                                              ((6,), (2, 3, 6)), ((4, 8), (4, 4, 8)), ((2, 3), (5, 2, 3))])
 @pytest.mark.parametrize("tag", ["f64", "f32"])
