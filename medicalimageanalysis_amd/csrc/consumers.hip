@@ -311,17 +311,113 @@ __global__ __launch_bounds__(256) void build_torus_kernel(const T* __restrict__ 
   }
 }
 
+// fp32 rows of three components, every array 16-byte aligned: a wave takes one tile of 256 rows.  Each (256, 3) array
+// moves between HBM and the wave as three fully coalesced 1 KiB accesses (all inputs sent for before any is used) and
+// is re-dealt through a wave-private LDS slab so that lane l owns rows 4 l .. 4 l + 3; the results leave the same way.
+// The thread-per-row kernel above reads and writes 4-byte elements 12 bytes apart from lane to lane -- seven such
+// accesses per row, and the address unit's time for them is that kernel's time.  Tiles are dealt so that an XCD works
+// on one contiguous eighth of the rows.  Same per-row functions, same bits.
+constexpr int BT_TILE = 256;
+__device__ __forceinline__ void bt_deal_in(u32x4* slab, const u32x4 (&u)[3], int lane, float (&a)[12]) {
+  u32x4 v[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) slab[lane + 64 * k] = u[k];
+  wave_lds_sync();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) v[k] = slab[3 * lane + k];
+  wave_lds_sync();
+  __builtin_memcpy(a, v, 48);
+}
+__device__ __forceinline__ void bt_deal_out(u32x4* slab, const float (&a)[12], int lane, float* dst) {
+  u32x4 v[3];
+  __builtin_memcpy(v, a, 48);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) slab[3 * lane + k] = v[k];
+  wave_lds_sync();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) v[k] = slab[lane + 64 * k];
+  wave_lds_sync();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    f32x4 f;
+    __builtin_memcpy(&f, &v[k], 16);
+    store_nt(f, dst + 4 * (lane + 64 * k));
+  }
+}
+template <bool BWD>
+__global__ __launch_bounds__(256) void build_torus_tile_kernel(const float* __restrict__ zt, const float* __restrict__ zp,
+                                                               const float* __restrict__ gout, float* __restrict__ out,
+                                                               float* __restrict__ gt, float* __restrict__ gp,
+                                                               int64_t ntiles, float R, float r) {
+  __shared__ u32x4 s_slab[4][3 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32x4* const slab = s_slab[wave];
+  const int64_t t = (int64_t)xcd_block(blockIdx.x, gridDim.x) * 4 + wave;
+  if (t >= ntiles) return;  // (no workgroup barrier in this kernel)
+  const int64_t e0 = 3 * BT_TILE * t;
+  u32x4 ut[3], up[3], ug[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) ut[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(zt + e0) + lane + 64 * k);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) up[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(zp + e0) + lane + 64 * k);
+  if (BWD) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ug[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(gout + e0) + lane + 64 * k);
+  }
+  float a[12], b[12], g[12], o[12], o2[12];
+  bt_deal_in(slab, ut, lane, a);
+  bt_deal_in(slab, up, lane, b);
+  if (BWD) bt_deal_in(slab, ug, lane, g);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float ct = a[3 * j], st = a[3 * j + 1], cp = b[3 * j], sp = b[3 * j + 1];
+    if (!BWD) {
+      torus_point<float>(ct, st, cp, sp, R, r, o + 3 * j);
+    } else {
+      float da[2], db[2];
+      torus_point_bwd<float>(ct, cp, sp, R, r, g + 3 * j, da, db);
+      o[3 * j] = da[0]; o[3 * j + 1] = da[1]; o[3 * j + 2] = 0.0f;
+      o2[3 * j] = db[0]; o2[3 * j + 1] = db[1]; o2[3 * j + 2] = 0.0f;
+    }
+  }
+  if (!BWD) {
+    bt_deal_out(slab, o, lane, out + e0);
+  } else {
+    bt_deal_out(slab, o, lane, gt + e0);
+    bt_deal_out(slab, o2, lane, gp + e0);
+  }
+}
+static inline bool bt_tile_ok(int dtype, int zdim, int64_t n, const void* a, const void* b, const void* c, const void* d,
+                              const void* e) {
+  const auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  return dtype == VMF_F32 && zdim == 3 && n >= BT_TILE && al(a) && al(b) && al(c) && al(d) && al(e) &&
+         (n / BT_TILE + 3) / 4 < 0x7fffffff;
+}
+
 extern "C" int vmf_build_torus_fwd(const void* z_theta, const void* z_phi, void* out, int64_t n, int zdim, double R,
                                    double r, int dtype, vmf_stream_t stream) {
   VMF_RANGE("vmf_build_torus_fwd");
   VMF_REQUIRE(n >= 0 && zdim >= 2, VMF_ERR_BAD_ARG, "vmf_build_torus_fwd: n %lld, zdim %d", (long long)n, zdim);
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(z_theta && z_phi && out, VMF_ERR_BAD_ARG, "vmf_build_torus_fwd: null pointer");
-  int grid = vmf_grid_for(n, 256);
+  int64_t done = 0;  // rows the tile kernel takes; the thread-per-row kernel takes the rest
+  if (bt_tile_ok(dtype, zdim, n, z_theta, z_phi, out, nullptr, nullptr)) {
+    const int64_t ntiles = n / BT_TILE;
+    hipLaunchKernelGGL((build_torus_tile_kernel<false>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)z_theta, (const float*)z_phi, (const float*)nullptr,
+                       (float*)out, (float*)nullptr, (float*)nullptr, ntiles, (float)R, (float)r);
+    done = ntiles * BT_TILE;
+    if (done == n) return vmf_check_launch("vmf_build_torus_fwd");
+  }
+  const int es = dtype == VMF_F32 ? 4 : 8;
+  const char* zt_ = (const char*)z_theta + done * zdim * es;
+  const char* zp_ = (const char*)z_phi + done * zdim * es;
+  char* out_ = (char*)out + done * 3 * es;
+  int grid = vmf_grid_for(n - done, 256);
   VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((build_torus_kernel<T, false>), dim3(grid), dim3(256), 0,
-                                               (hipStream_t)stream, (const T*)z_theta, (const T*)z_phi,
-                                               (const T*)nullptr, (T*)out, (T*)nullptr, (T*)nullptr, n, zdim, (T)R,
-                                               (T)r));
+                                               (hipStream_t)stream, (const T*)zt_, (const T*)zp_,
+                                               (const T*)nullptr, (T*)out_, (T*)nullptr, (T*)nullptr, n - done, zdim,
+                                               (T)R, (T)r));
   return vmf_check_launch("vmf_build_torus_fwd");
 }
 
@@ -332,10 +428,25 @@ extern "C" int vmf_build_torus_bwd(const void* z_theta, const void* z_phi, const
   VMF_REQUIRE(n >= 0 && zdim >= 2, VMF_ERR_BAD_ARG, "vmf_build_torus_bwd: n %lld, zdim %d", (long long)n, zdim);
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(z_theta && z_phi && grad_out && g_theta && g_phi, VMF_ERR_BAD_ARG, "vmf_build_torus_bwd: null pointer");
-  int grid = vmf_grid_for(n, 256);
+  int64_t done = 0;
+  if (bt_tile_ok(dtype, zdim, n, z_theta, z_phi, grad_out, g_theta, g_phi)) {
+    const int64_t ntiles = n / BT_TILE;
+    hipLaunchKernelGGL((build_torus_tile_kernel<true>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)z_theta, (const float*)z_phi, (const float*)grad_out,
+                       (float*)nullptr, (float*)g_theta, (float*)g_phi, ntiles, (float)R, (float)r);
+    done = ntiles * BT_TILE;
+    if (done == n) return vmf_check_launch("vmf_build_torus_bwd");
+  }
+  const int es = dtype == VMF_F32 ? 4 : 8;
+  const char* zt_ = (const char*)z_theta + done * zdim * es;
+  const char* zp_ = (const char*)z_phi + done * zdim * es;
+  const char* go_ = (const char*)grad_out + done * 3 * es;
+  char* gt_ = (char*)g_theta + done * zdim * es;
+  char* gp_ = (char*)g_phi + done * zdim * es;
+  int grid = vmf_grid_for(n - done, 256);
   VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((build_torus_kernel<T, true>), dim3(grid), dim3(256), 0,
-                                               (hipStream_t)stream, (const T*)z_theta, (const T*)z_phi,
-                                               (const T*)grad_out, (T*)nullptr, (T*)g_theta, (T*)g_phi, n, zdim,
+                                               (hipStream_t)stream, (const T*)zt_, (const T*)zp_,
+                                               (const T*)go_, (T*)nullptr, (T*)gt_, (T*)gp_, n - done, zdim,
                                                (T)R, (T)r));
   return vmf_check_launch("vmf_build_torus_bwd");
 }

@@ -204,6 +204,39 @@ def test_build_torus_matches_goldens(golden, tag, name):
     np.testing.assert_allclose(N(zp.grad), g[k + "g_zp"], **TOL[tag])
 
 
+def test_build_torus_tile_kernel_and_row_kernel_give_the_same_bits():
+    """fp32 rows of three components, 16-byte aligned: full tiles of 256 rows take the kernel that moves whole tiles, the
+    tail and every other layout the thread-per-row kernel -- the same rows through both (aligned; a view that starts one
+    element into its buffer) agree bit for bit, forward and backward, and match the formula in double precision"""
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    n = 256 * 37 + 101
+    zt = torch.nn.functional.normalize(torch.randn(n, 3, device=DEV, generator=gen), dim=-1)
+    zp = torch.nn.functional.normalize(torch.randn(n, 3, device=DEV, generator=gen), dim=-1)
+    c = torch.randn(n, 3, device=DEV, generator=gen)
+
+    def run(a, b):
+        a, b = a.detach().requires_grad_(), b.detach().requires_grad_()
+        out = losses.build_torus(a, b, 1.5, 0.5)
+        (out * c).sum().backward()
+        return out.detach(), a.grad, b.grad
+
+    def off(t):
+        buf = torch.empty(t.numel() + 1, device=DEV)
+        v = buf[1:].view(t.shape)
+        v.copy_(t)
+        return v
+
+    got = run(zt, zp)
+    assert zt.data_ptr() % 16 == 0
+    got_row = run(off(zt), off(zp))
+    for x, y in zip(got, got_row):
+        assert torch.equal(x, y)
+    ct, st, cp, sp = zt[:, 0].double(), zt[:, 1].double(), zp[:, 0].double(), zp[:, 1].double()
+    ref = torch.stack([(1.5 + 0.5 * ct) * cp, (0.5 + 0.5 * ct) * sp, 0.5 * st], dim=-1)
+    np.testing.assert_allclose(N(got[0]), N(ref), rtol=1e-6, atol=1e-6)
+    assert float(got[1][:, 2].abs().max()) == 0.0 and float(got[2][:, 2].abs().max()) == 0.0
+
+
 def test_build_torus_model_method_and_broadcast():
     cfg = dict(extrinsic_dim=6, latent_dim=3, sftbeta=1.0, encoder_width=8, encoder_depth=1, decoder_width=8,
                decoder_depth=1, dropout_p=0.0, device="cuda", gamma=1.0, beta=0.1, longest_radius=1.5,
