@@ -317,7 +317,14 @@ __global__ __launch_bounds__(KL_BLOCK) void kl_fwd_kernel(const T* __restrict__ 
 #pragma unroll
     for (int u = 0; u < KL_UNROLL; ++u) {
       const int64_t i = base + u * blockDim.x + threadIdx.x;
-      if (i < nvec) k4[u] = *reinterpret_cast<const Vec4<T>*>(kappa + 4 * i);
+      if (i < nvec) {
+        if constexpr (sizeof(T) == 4) {  // read once: past the caches
+          const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kappa + 4 * i));
+          k4[u].v[0] = v.x; k4[u].v[1] = v.y; k4[u].v[2] = v.z; k4[u].v[3] = v.w;
+        } else {
+          k4[u] = *reinterpret_cast<const Vec4<T>*>(kappa + 4 * i);
+        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < KL_UNROLL; ++u) {
