@@ -572,6 +572,144 @@ __global__ __launch_bounds__(256) void sphere_uniform_kernel(const T* __restrict
   }
 }
 
+// Rows of up to 16 floats, fp32, in-kernel noise: ONE lane owns a row.  Its normals are drawn once and stay in
+// registers (the kernel above walks a row twice, drawing its noise both times, and stores 4-byte elements a row apart
+// from lane to lane: 1.0-1.8 TB/s); the wave's tile is written into a wave-private LDS slab and leaves as a flat array
+// of 16-byte units, fully coalesced whatever the row width.  Same counters, same normals; the norm through the hardware
+// reciprocal square root.
+template <int D>
+__global__ __launch_bounds__(256) void sphere_uniform_rows_kernel(float* __restrict__ out, int64_t n, uint64_t row0,
+                                                                  PhiloxArg ka, int aligned) {
+  constexpr int TILE = D <= 4 ? 256 : (D <= 8 ? 128 : 64);  // rows per wave: the slab stays at 2-4 KiB
+  constexpr int UNITS = TILE * D / 4, UPL = (UNITS + 63) / 64, CHUNKS = (D + 3) / 4;
+  __shared__ __align__(16) float s_rows[4][TILE * D];
+  const PhiloxKey key = philox_resolve(ka);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* const srow = s_rows[wave];
+  const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * TILE;
+  if (tile0 >= n) return;  // (no workgroup barrier in this kernel)
+  const int64_t left = n - tile0;
+  const int ntile = left < TILE ? (int)left : TILE;
+#pragma unroll
+  for (int sub = 0; sub < TILE / 64; ++sub) {
+    const int r = sub * 64 + lane;
+    if (r < ntile) {
+      float g[4 * CHUNKS];
+#pragma unroll
+      for (int c = 0; c < CHUNKS; ++c)
+        philox_normal4<float>(row0 + (uint64_t)(tile0 + r), 0x20000u + (uint32_t)c, key, g + 4 * c);
+      float ss = 0.0f;
+#pragma unroll
+      for (int e = 0; e < D; ++e) ss += g[e] * g[e];
+      const float inv = F<float>::rsqrt(ss);  // sampler/spherical_uniform.py:33, no epsilon
+#pragma unroll
+      for (int e = 0; e < D; ++e) srow[r * D + e] = g[e] * inv;
+    }
+  }
+  wave_lds_sync();
+  float* const dst = out + tile0 * D;
+  if (aligned && ntile == TILE) {
+#pragma unroll
+    for (int s = 0; s < UPL; ++s) {
+      const int q = lane + 64 * s;
+      if (UNITS % 64 == 0 || q < UNITS) store_nt(reinterpret_cast<const f32x4*>(srow)[q], dst + 4 * q);
+    }
+  } else {
+    for (int e = lane; e < ntile * D; e += 64) dst[e] = srow[e];
+  }
+}
+// Wider rows (17 .. 1024 floats), fp32, in-kernel noise: a row is split over LPR lanes (the smallest power of two that
+// holds its four-element chunks, at most 64) x up to four passes; a lane draws its chunks once, the squared norm is
+// summed inside the lane group with xor shuffles, and every chunk leaves as one 16-byte store when rows are whole
+// chunks and aligned (guarded 4-byte stores otherwise).  A wave takes SU_STEPS consecutive steps of 64 / LPR rows.
+constexpr int SU_STEPS = 8, SU_MAX_PASSES = 4;
+// four consecutive floats with the alignment of one: a whole chunk of a row that is not 16-byte aligned still moves as
+// one access
+struct __attribute__((packed, aligned(4))) SuQuad {
+  float v[4];
+};
+__global__ __launch_bounds__(256) void sphere_uniform_wide_kernel(float* __restrict__ out, int64_t n, int dim, int lpr,
+                                                                  uint64_t row0, PhiloxArg ka, int vec) {
+  const PhiloxKey key = philox_resolve(ka);
+  const int lane = threadIdx.x & 63;
+  const int rpi = 64 / lpr, sub = lane & (lpr - 1), grp = lane / lpr;
+  const int chunks = (dim + 3) / 4;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t n_steps = (n + rpi - 1) / rpi;
+  const int64_t step_end = (wave_id + 1) * SU_STEPS < n_steps ? (wave_id + 1) * SU_STEPS : n_steps;
+  for (int64_t step = wave_id * SU_STEPS; step < step_end; ++step) {  // wave-uniform
+    const int64_t r = step * rpi + grp;
+    const bool valid = r < n;
+    const int64_t row = valid ? r : 0;  // lanes past the end draw row 0 again (the shuffles need the whole wave) and store nothing
+    float g[SU_MAX_PASSES][4];
+    float ss = 0.0f;
+#pragma unroll
+    for (int p = 0; p < SU_MAX_PASSES; ++p) {
+      const int c = p * lpr + sub;
+      if (c < chunks) {
+        philox_normal4<float>(row0 + (uint64_t)row, 0x20000u + (uint32_t)c, key, g[p]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (4 * c + i >= dim) g[p][i] = 0.0f;
+          ss += g[p][i] * g[p][i];
+        }
+      }
+    }
+    for (int o = 1; o < lpr; o <<= 1) ss += __shfl_xor(ss, o, 64);
+    const float inv = F<float>::rsqrt(ss);  // sampler/spherical_uniform.py:33, no epsilon
+    if (valid) {
+      float* const orow = out + row * dim;
+#pragma unroll
+      for (int p = 0; p < SU_MAX_PASSES; ++p) {
+        const int c = p * lpr + sub;
+        if (c < chunks) {
+          if (vec) {
+            store_nt(f32x4{g[p][0] * inv, g[p][1] * inv, g[p][2] * inv, g[p][3] * inv}, orow + 4 * c);
+          } else if (4 * c + 4 <= dim) {
+            SuQuad q;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q.v[i] = g[p][i] * inv;
+            *reinterpret_cast<SuQuad*>(orow + 4 * c) = q;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (4 * c + i < dim) orow[4 * c + i] = g[p][i] * inv;
+          }
+        }
+      }
+    }
+  }
+}
+static bool launch_sphere_uniform_wide(float* out, int64_t n, int dim, uint64_t row0, const PhiloxArg& key,
+                                       hipStream_t s) {
+  const int chunks = (dim + 3) / 4;
+  if (dim <= 16 || chunks > 64 * SU_MAX_PASSES) return false;
+  int lpr = 1;
+  while (lpr < chunks && lpr < 64) lpr <<= 1;
+  const int64_t steps = (n + 64 / lpr - 1) / (64 / lpr);
+  const int64_t blocks = ((steps + SU_STEPS - 1) / SU_STEPS + 3) / 4;
+  if (blocks >= 0x7fffffff) return false;
+  const int vec = (dim % 4 == 0 && ew_aligned16(out)) ? 1 : 0;
+  hipLaunchKernelGGL(sphere_uniform_wide_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, n, dim, lpr, row0, key,
+                     vec);
+  return true;
+}
+static bool launch_sphere_uniform_rows(float* out, int64_t n, int dim, uint64_t row0, const PhiloxArg& key,
+                                       hipStream_t s) {
+  const int tile = dim <= 4 ? 256 : (dim <= 8 ? 128 : 64);
+  const int64_t blocks = ((n + tile - 1) / tile + 3) / 4;
+  if (blocks >= 0x7fffffff) return false;
+  const int aligned = ew_aligned16(out) ? 1 : 0;
+  const dim3 grid((unsigned)blocks), block(256);
+  switch (dim) {
+#define VMF_SU(D) case D: hipLaunchKernelGGL((sphere_uniform_rows_kernel<D>), grid, block, 0, s, out, n, row0, key, aligned); return true
+    VMF_SU(2); VMF_SU(3); VMF_SU(4); VMF_SU(5); VMF_SU(6); VMF_SU(7); VMF_SU(8); VMF_SU(9); VMF_SU(10); VMF_SU(11);
+    VMF_SU(12); VMF_SU(13); VMF_SU(14); VMF_SU(15); VMF_SU(16);
+#undef VMF_SU
+    default: return false;
+  }
+}
+
 extern "C" int vmf_sphere_uniform_sample(const void* gauss, void* out, int64_t n, int dim, uint64_t row0,
                                          uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int dtype,
                                          vmf_stream_t stream) {
@@ -580,6 +718,10 @@ extern "C" int vmf_sphere_uniform_sample(const void* gauss, void* out, int64_t n
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(out, VMF_ERR_BAD_ARG, "vmf_sphere_uniform_sample: null out");
   PhiloxArg key = make_philox_arg(seed, offset, offset_dev);
+  if (dtype == VMF_F32 && !gauss &&
+      (launch_sphere_uniform_rows((float*)out, n, dim, row0, key, (hipStream_t)stream) ||
+       launch_sphere_uniform_wide((float*)out, n, dim, row0, key, (hipStream_t)stream)))
+    return vmf_check_launch("vmf_sphere_uniform_sample");
   int grid = vmf_grid_for(n, 256);
   VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(sphere_uniform_kernel<T>, dim3(grid), dim3(256), 0,
                                                (hipStream_t)stream, (const T*)gauss, (T*)out, n, dim, row0, key));

@@ -736,6 +736,33 @@ def test_s1_and_uniform_counter_noise_streams(oracle, tag, dim):
     np.testing.assert_allclose(N(out), gs / np.linalg.norm(gs, axis=1, keepdims=True), rtol=0, atol=tol)
 
 
+@pytest.mark.parametrize("dim", [2, 3, 4, 7, 10, 16, 17, 20, 64, 65, 260, 1024, 1030])
+def test_uniform_prior_every_kernel_same_stream(oracle, dim):
+    """the uniform prior in fp32 with in-kernel noise: rows of up to 16 floats take the lane-per-row kernel, up to 1024
+    the lane-group kernel, wider ones the general one -- every one of them must reproduce the oracle's stream (slot
+    family 0x20000), for ragged row counts, a misaligned output view, and a shard must equal the rows of the whole"""
+    lib, sp = _lib.lib(), _lib.stream_ptr(DEV)
+    n, row0, seed, offset = 64 * 9 + 37, (1 << 33) + 5, 0xABCDEF0123456789, (3 << 32) + 17
+    rows = [row0 + i for i in range(n)]
+    gs = _philox_normals(oracle, rows, 0x20000, seed, offset, dim)
+    want = gs / np.linalg.norm(gs, axis=1, keepdims=True)
+
+    def run(out, cnt, r0):
+        _lib.check(lib.vmf_sphere_uniform_sample(None, _lib.ptr(out), cnt, dim, r0, seed, offset, None, _lib.VMF_F32, sp),
+                   "vmf_sphere_uniform_sample")
+        return out
+
+    whole = run(torch.full((n, dim), float("nan"), device=DEV), n, row0)
+    np.testing.assert_allclose(N(whole), want, rtol=0, atol=2e-6)
+    assert float((whole.norm(dim=-1) - 1).abs().max()) < 1e-6
+    buf = torch.full((n * dim + 2,), float("nan"), device=DEV)
+    view = run(buf[1:1 + n * dim].view(n, dim), n, row0)           # 4-byte aligned only
+    assert torch.equal(view, whole) and bool(torch.isnan(buf[0])) and bool(torch.isnan(buf[-1]))
+    lo = 101
+    shard = run(torch.full((n - lo, dim), float("nan"), device=DEV), n - lo, row0 + lo)
+    assert torch.equal(shard, whole[lo:])
+
+
 # ---- general m ----------------------------------------------------------------------------------------------------
 def _call_rsample_pre(mu, kappa, pe, pu, ga, dtype):
     n, m = mu.shape
