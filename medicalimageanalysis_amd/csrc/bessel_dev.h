@@ -253,7 +253,8 @@ static inline int ive_kind_of(const BesselOrder& o) {
 // exponential: ive = exp(E) P with
 //   series   P = sum_k a_k q^k,                  E = v log(x/2) - lgamma(v+1) - x
 //   uniform  P = sum_n d_n t^n sqrt(t / 2 pi),   E = (r - x) - v log((v + r)/x)
-VMF_HD double ive_pos_tab(const IveTab& tab, double v, double lgam_v1, double x) {
+// (E, P) of ive = exp(E) P: what ive itself, its logarithm and ratios of two orders are made of
+VMF_HD void ive_pos_tab_parts(const IveTab& tab, double v, double lgam_v1, double x, double* E_out, double* P_out) {
   const double r2 = ::fma(x, x, v * v);
   double P, larg, e0;
   if (r2 < VMF_DEBYE_R2) {
@@ -275,8 +276,26 @@ VMF_HD double ive_pos_tab(const IveTab& tab, double v, double lgam_v1, double x)
     e0 = v * v * rcp_nr(r + x);  // r - x without cancellation
   }
   const double L = ::log(larg);
-  const double E = r2 < VMF_DEBYE_R2 ? ::fma(v, L, e0) : ::fma(-v, L, e0);
+  *E_out = r2 < VMF_DEBYE_R2 ? ::fma(v, L, e0) : ::fma(-v, L, e0);
+  *P_out = P;
+}
+VMF_HD double ive_pos_tab(const IveTab& tab, double v, double lgam_v1, double x) {
+  double E, P;
+  ive_pos_tab_parts(tab, v, lgam_v1, x, &E, &P);
   return ::exp(E) * P;
+}
+// The log-domain quantities from the same tables (x > 0; beyond VMF_IVE_TAB_XMAX the rolled expansions further up take
+// over: r^2 would leave the range the Newton steps of the reciprocal root are good for):
+//   log ive(v, x) = E + log P                       two logarithms, no loop over terms
+//   I_v / I_{v-1} = exp(E_v - E_{v-1}) P_v / P_{v-1}   (tables of both orders; each order picks its own region)
+// against a power series of up to 400 terms / thirteen nested polynomial loops with three logarithms, and a continued
+// fraction of up to 500 divisions.  Accuracy as ive's: the error of v log(.) in the exponent (1e-13 at v = 255).
+#define VMF_IVE_TAB_XMAX 1.0e9
+VMF_HD double log_ive_pos_tab(const IveTab& tab, double v, double lgam_v1, double x) {
+  if (!(x <= VMF_IVE_TAB_XMAX)) return log_ive_pos(v, lgam_v1, x);
+  double E, P;
+  ive_pos_tab_parts(tab, v, lgam_v1, x, &E, &P);
+  return E + ::log(P);
 }
 // ive(v, z) with scipy's edge conventions (as ive_eval) for a launch of the given kind
 template <int KIND>
@@ -331,6 +350,16 @@ VMF_HD double bessel_ratio_eval(double v, double lg_v1, double lg_v, double x) {
     return f;
   }
   return ::exp(log_ive_pos(v, lg_v1, x) - log_ive_pos(v - 1.0, lg_v, x));
+}
+
+// the same ratio from the tables of the orders v (tab1) and v - 1 (tab0)
+VMF_HD double bessel_ratio_tab(const IveTab& tab1, const IveTab& tab0, double v, double lg_v1, double lg_v, double x) {
+  if (x == 0) return 0.0;
+  if (!(x <= VMF_IVE_TAB_XMAX)) return bessel_ratio_eval(v, lg_v1, lg_v, x);
+  double E1, P1, E0, P0;
+  ive_pos_tab_parts(tab1, v, lg_v1, x, &E1, &P1);
+  ive_pos_tab_parts(tab0, v - 1.0, lg_v, x, &E0, &P0);
+  return ::exp(E1 - E0) * P1 * rcp_nr(P0);
 }
 
 // ---- single-precision log ive for the fp32 log-normaliser (one evaluation per ROW of a 2^24-row batch) ---------
@@ -404,4 +433,34 @@ VMF_HD float vmf_log_norm_f32(const VmfDim& d, float k) {
 // A_m(k) = I_{m/2}(k) / I_{m/2-1}(k)
 VMF_HD double vmf_mean_resultant(const VmfDim& d, double k) {
   return bessel_ratio_eval(d.v + 1.0, d.lg_v2, d.lg_v1, k);
+}
+// Both through the coefficient tables of the orders m/2 - 1 and m/2 (built once per launch on the host, read through
+// scalar loads): what the double-precision kernels evaluate per element
+struct VmfDimTab {
+  IveTab t0, t1;
+};
+static inline VmfDimTab make_vmf_dim_tab(const VmfDim& d) {
+  VmfDimTab t;
+  t.t0 = make_ive_tab(make_bessel_order(d.v, 0));
+  t.t1 = make_ive_tab(make_bessel_order(d.v + 1.0, 0));
+  return t;
+}
+VMF_HD double vmf_log_norm_tab(const VmfDim& d, const VmfDimTab& t, double k) {
+  return d.v * ::log(k) - d.half_m_log2pi - (log_ive_pos_tab(t.t0, d.v, d.lg_v1, k) + k);
+}
+VMF_HD double vmf_mean_resultant_tab(const VmfDim& d, const VmfDimTab& t, double k) {
+  return bessel_ratio_tab(t.t1, t.t0, d.v + 1.0, d.lg_v2, d.lg_v1, k);
+}
+// log C_m(k) and A_m(k) together: the order m/2 - 1 is evaluated once
+VMF_HD void vmf_log_norm_and_resultant_tab(const VmfDim& d, const VmfDimTab& t, double k, double* logc, double* A) {
+  if (!(k > 0.0 && k <= VMF_IVE_TAB_XMAX)) {
+    *logc = vmf_log_norm(d, k);
+    *A = vmf_mean_resultant(d, k);
+    return;
+  }
+  double E0, P0, E1, P1;
+  ive_pos_tab_parts(t.t0, d.v, d.lg_v1, k, &E0, &P0);
+  ive_pos_tab_parts(t.t1, d.v + 1.0, d.lg_v2, k, &E1, &P1);
+  *logc = d.v * ::log(k) - d.half_m_log2pi - (E0 + ::log(P0) + k);
+  *A = ::exp(E1 - E0) * P1 * rcp_nr(P0);
 }

@@ -37,21 +37,22 @@ __global__ __launch_bounds__(256) void ive_bwd_kernel(const T* __restrict__ z, c
 
 template <typename T>
 __global__ __launch_bounds__(256) void log_ive_kernel(const T* __restrict__ z, T* __restrict__ out, int64_t n,
-                                                      double v, double lg_v1) {
+                                                      double v, double lg_v1, IveTab tab) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     double x = (double)z[i];
-    out[i] = (T)(x > 0 ? log_ive_pos(v, lg_v1, x) : (x == 0 ? (v == 0 ? 0.0 : -INFINITY) : NAN));
+    out[i] = (T)(x > 0 ? log_ive_pos_tab(tab, v, lg_v1, x) : (x == 0 ? (v == 0 ? 0.0 : -INFINITY) : NAN));
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void bessel_ratio_kernel(const T* __restrict__ z, T* __restrict__ out,
-                                                           int64_t n, double v, double lg_v1, double lg_v) {
+                                                           int64_t n, double v, double lg_v1, double lg_v,
+                                                           IveTab tab1, IveTab tab0) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     double x = (double)z[i];
-    out[i] = (T)(x >= 0 ? bessel_ratio_eval(v, lg_v1, lg_v, x) : NAN);
+    out[i] = (T)(x >= 0 ? bessel_ratio_tab(tab1, tab0, v, lg_v1, lg_v, x) : NAN);
   }
 }
 
@@ -115,7 +116,7 @@ extern "C" int vmf_log_ive_fwd(double v, const void* z, void* out, int64_t n, in
   int grid = vmf_grid_for(n, 256);
   double lg = lgamma(v + 1.0);
   VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(log_ive_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                               (const T*)z, (T*)out, n, v, lg));
+                                               (const T*)z, (T*)out, n, v, lg, make_ive_tab(make_bessel_order(v, 0))));
   return vmf_check_launch("vmf_log_ive_fwd");
 }
 
@@ -129,7 +130,9 @@ extern "C" int vmf_bessel_ratio_fwd(double v, const void* z, void* out, int64_t 
   int grid = vmf_grid_for(n, 256);
   double lg1 = lgamma(v + 1.0), lg0 = lgamma(v);
   VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bessel_ratio_kernel<T>, dim3(grid), dim3(256), 0,
-                                               (hipStream_t)stream, (const T*)z, (T*)out, n, v, lg1, lg0));
+                                               (hipStream_t)stream, (const T*)z, (T*)out, n, v, lg1, lg0,
+                                               make_ive_tab(make_bessel_order(v, 0)),
+                                               make_ive_tab(make_bessel_order(v - 1.0, 0))));
   return vmf_check_launch("vmf_bessel_ratio_fwd");
 }
 

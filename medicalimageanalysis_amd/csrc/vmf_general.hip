@@ -1559,13 +1559,14 @@ static void launch_bwd_rowlane(const GenParams<float>& p, hipStream_t s) {
 // out of the streaming kernel)
 template <typename T>
 __global__ __launch_bounds__(256) void vmf_log_norm_kernel(const T* __restrict__ kappa, int64_t kappa_stride,
-                                                           T* __restrict__ out, int64_t n, VmfDim dim, int softplus) {
+                                                           T* __restrict__ out, int64_t n, VmfDim dim, VmfDimTab tab,
+                                                           int softplus) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     T sig_;
     const T kap = kappa_of<T>(kappa[i * kappa_stride], softplus != 0, &sig_);
     if (sizeof(T) == 4) out[i] = (T)vmf_log_norm_f32(dim, (float)kap);
-    else out[i] = (T)vmf_log_norm(dim, (double)kap);
+    else out[i] = (T)vmf_log_norm_tab(dim, tab, (double)kap);
   }
 }
 
@@ -1663,7 +1664,7 @@ static int rsample_fwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   }
   if (logp_out && sizeof(T) == 8)
     hipLaunchKernelGGL(vmf_log_norm_kernel<T>, dim3(vmf_grid_for(n, 256)), dim3(256), 0, s, (const T*)kappa,
-                       kappa_stride, (T*)logp_out, n, make_vmf_dim(m), p.softplus);
+                       kappa_stride, (T*)logp_out, n, make_vmf_dim(m), make_vmf_dim_tab(make_vmf_dim(m)), p.softplus);
   const bool pair_ok = m == 2 && !prop_e && !gauss && mu_stride % 2 == 0 && ((uintptr_t)mu % (2 * sizeof(T))) == 0 &&
                        ((uintptr_t)z % (2 * sizeof(T))) == 0;
   if constexpr (sizeof(T) == 4) {
@@ -1814,13 +1815,13 @@ extern "C" int vmf_rsample_bwd(const void* mu, int64_t mu_stride, const void* ka
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void vmf_log_prob_rowterm_kernel(const T* __restrict__ kappa, int64_t kappa_stride,
                                                                     const T* __restrict__ gl, T* __restrict__ out,
-                                                                    int64_t n, VmfDim dim) {
+                                                                    int64_t n, VmfDim dim, VmfDimTab tab) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const double k = (double)kappa[i * kappa_stride];
     if (!BWD) out[i] = sizeof(T) == 4 ? (T)(dim.m == 2 ? vmf_log_norm_circle_f32((float)k) : vmf_log_norm_f32(dim, (float)k))
-                                      : (T)vmf_log_norm(dim, k);
-    else out[i] = (T)(-(double)gl[i] * vmf_mean_resultant(dim, k));  // d log C_m / dk = -A_m(k)
+                                      : (T)vmf_log_norm_tab(dim, tab, k);
+    else out[i] = (T)(-(double)gl[i] * vmf_mean_resultant_tab(dim, tab, k));  // d log C_m / dk = -A_m(k)
   }
 }
 
@@ -1897,7 +1898,7 @@ static int log_prob_t(const void* mu, int64_t mu_stride, const void* kappa, int6
   T* rowterm = BWD ? (T*)dkappa : (T*)logp;
   if (rowterm)
     hipLaunchKernelGGL((vmf_log_prob_rowterm_kernel<T, BWD>), dim3(vmf_grid_for(n, 256)), dim3(256), 0, s, (const T*)kappa,
-                       kappa_stride, (const T*)gl, rowterm, n, dim);
+                       kappa_stride, (const T*)gl, rowterm, n, dim, make_vmf_dim_tab(dim));
   const bool vec = (m % 4 == 0) && (mu_stride % 4 == 0) && aligned16(mu) && aligned16(x) && (!dmu || aligned16(dmu)) &&
                    (!dx || aligned16(dx));
   const int chunks = (m + 3) / 4;
@@ -1949,12 +1950,13 @@ extern "C" int vmf_log_prob_bwd(const void* mu, int64_t mu_stride, const void* k
 template <typename T>
 __global__ __launch_bounds__(256) void vmf_entropy_kl_kernel(const T* __restrict__ kappa, T* __restrict__ entropy,
                                                              T* __restrict__ kl, T* __restrict__ dkl, int64_t n,
-                                                             VmfDim dim) {
+                                                             VmfDim dim, VmfDimTab tab) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const double k = (double)kappa[i];
-    const double A = vmf_mean_resultant(dim, k);
-    const double H = -vmf_log_norm(dim, k) - k * A;
+    double logc, A;
+    vmf_log_norm_and_resultant_tab(dim, tab, k, &logc, &A);
+    const double H = -logc - k * A;
     if (entropy) entropy[i] = (T)H;
     if (kl) kl[i] = (T)(-H + dim.log_area);
     // dKL/dk = k A'(k),  A' = 1 - A^2 - (m-1) A / k
@@ -1972,6 +1974,6 @@ extern "C" int vmf_entropy_kl_fwd(const void* kappa, void* entropy, void* kl, vo
   int grid = vmf_grid_for(n, 256);
   VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(vmf_entropy_kl_kernel<T>, dim3(grid), dim3(256), 0,
                                                (hipStream_t)stream, (const T*)kappa, (T*)entropy, (T*)kl,
-                                               (T*)dkl_dk, n, dim));
+                                               (T*)dkl_dk, n, dim, make_vmf_dim_tab(dim)));
   return vmf_check_launch("vmf_entropy_kl_fwd");
 }

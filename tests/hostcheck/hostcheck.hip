@@ -26,6 +26,28 @@ void hc_ratio(double v, const double* z, double* out, int64_t n) {
   double lg1 = lgamma(v + 1.0), lg0 = lgamma(v);
   for (int64_t i = 0; i < n; ++i) out[i] = bessel_ratio_eval(v, lg1, lg0, z[i]);
 }
+// the table-driven forms the kernels evaluate (tables as the entry points build them)
+void hc_log_ive_tab(double v, const double* z, double* out, int64_t n) {
+  const double lg = lgamma(v + 1.0);
+  const IveTab tab = make_ive_tab(make_bessel_order(v, 0));
+  for (int64_t i = 0; i < n; ++i) out[i] = log_ive_pos_tab(tab, v, lg, z[i]);
+}
+void hc_ratio_tab(double v, const double* z, double* out, int64_t n) {
+  const double lg1 = lgamma(v + 1.0), lg0 = lgamma(v);
+  const IveTab t1 = make_ive_tab(make_bessel_order(v, 0)), t0 = make_ive_tab(make_bessel_order(v - 1.0, 0));
+  for (int64_t i = 0; i < n; ++i) out[i] = bessel_ratio_tab(t1, t0, v, lg1, lg0, z[i]);
+}
+void hc_log_norm_tab(int m, const double* k, double* out, double* a_out, int64_t n) {
+  const VmfDim d = make_vmf_dim(m);
+  const VmfDimTab t = make_vmf_dim_tab(d);
+  for (int64_t i = 0; i < n; ++i) {
+    double lc, A;
+    vmf_log_norm_and_resultant_tab(d, t, k[i], &lc, &A);
+    out[i] = vmf_log_norm_tab(d, t, k[i]);
+    a_out[i] = A;
+    if (lc != out[i]) out[i] = NAN;  // the two spellings must agree exactly
+  }
+}
 void hc_log_norm(int m, const double* k, double* out, int64_t n) {
   VmfDim d = make_vmf_dim(m);
   for (int64_t i = 0; i < n; ++i) out[i] = vmf_log_norm(d, k[i]);

@@ -77,6 +77,27 @@ def test_device_log_ive_ratio_lognorm_match_oracle(hc, oracle):
         np.testing.assert_allclose(out, ref, rtol=1e-11, atol=1e-9)
 
 
+def test_device_table_driven_log_ive_ratio_lognorm_match_oracle(hc, oracle):
+    """the forms the double-precision kernels evaluate: E + log P and exp(E_v - E_{v-1}) P_v / P_{v-1} from the per-order
+    coefficient tables, on a dense grid that crosses the series / uniform-expansion boundary of both orders and runs past
+    the tables' range (x > 1e9 falls back to the rolled expansions)"""
+    x = np.concatenate([np.logspace(-8, 10, 1441), np.linspace(20.0, 40.0, 801)])
+    lib = oracle.lib()
+    for v in (0.0, 0.5, 1.0, 1.5, 4.0, 4.5, 15.0, 29.5, 30.0, 31.0, 32.0, 127.5, 255.0, 256.0, 511.0, 1023.0):
+        np.testing.assert_allclose(_unary(hc.hc_log_ive_tab, v, x), oracle.log_ive(v, x), rtol=0,
+                                   atol=3e-12 * (1 + v), err_msg=f"v={v}")
+        if v >= 1:
+            np.testing.assert_allclose(_unary(hc.hc_ratio_tab, v, x), oracle.bessel_ratio(v, x), rtol=2e-10,
+                                       err_msg=f"ratio v={v}")
+    for m in (2, 3, 4, 10, 64, 65, 512, 2048):
+        k = np.logspace(-6, 9.5, 621)
+        out, a = np.empty_like(k), np.empty_like(k)
+        hc.hc_log_norm_tab(m, _p(k), _p(out), _p(a), C.c_int64(k.size))
+        ref = np.array([lib.orc_vmf_log_norm_scalar(m, kk) for kk in k])
+        np.testing.assert_allclose(out, ref, rtol=1e-11, atol=1e-9, err_msg=f"m={m}")
+        np.testing.assert_allclose(a, oracle.bessel_ratio(0.5 * m, k), rtol=2e-10, err_msg=f"A m={m}")
+
+
 def test_device_single_precision_log_normaliser(hc, oracle):
     """the fp32 log C_m(kappa) used for fp32 log_prob outputs: within fp32 rounding of the double oracle"""
     lib = oracle.lib()
