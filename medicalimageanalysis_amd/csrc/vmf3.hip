@@ -490,17 +490,16 @@ __global__ __launch_bounds__(256) void vmf3_log_prob_ref_kernel(const T* __restr
                                                                 T* __restrict__ lognorm, int64_t n) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    T k = scale[i];
-    // CNN_experiment/von_mises_fisher.py:103-108
-    T ln = M<T>::log(k) - (T)2.5310242469692907 /* log(4 pi) */ - M<T>::log(M<T>::sinh(k) + (T)1e-10);
-    if (lognorm) lognorm[i] = ln;
+    const T k = scale[i];
+    T ln;
     if (logp) {
-      T r[3] = {loc[3 * i], loc[3 * i + 1], loc[3 * i + 2]};
-      T l[3], nn;
-      v3_normalise_loc<T>(r, l, &nn);
-      T dot = l[0] * x[3 * i] + l[1] * x[3 * i + 1] + l[2] * x[3 * i + 2];
-      logp[i] = k * dot - ln;  // :92-95 (the reference subtracts)
+      const T r[3] = {loc[3 * i], loc[3 * i + 1], loc[3 * i + 2]};
+      const T xv[3] = {x[3 * i], x[3 * i + 1], x[3 * i + 2]};
+      logp[i] = v3_log_prob_ref_row<T>(r, k, xv, &ln);
+    } else {
+      v3_log_norm_ref<T>(k, &ln, (T*)nullptr);  // CNN_experiment/von_mises_fisher.py:103-108
     }
+    if (lognorm) lognorm[i] = ln;
   }
 }
 
@@ -510,10 +509,20 @@ extern "C" int vmf3_log_prob_ref(const void* loc, const void* scale, const void*
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(scale && (!logp || (loc && x)), VMF_ERR_BAD_ARG, "vmf3_log_prob_ref: null pointer");
-  int grid = vmf_grid_for(n, 256);
-  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(vmf3_log_prob_ref_kernel<T>, dim3(grid), dim3(256), 0,
-                                               (hipStream_t)stream, (const T*)loc, (const T*)scale, (const T*)x,
-                                               (T*)logp, (T*)lognorm, n));
+  VMF_REQUIRE(dtype == VMF_F32 || dtype == VMF_F64, VMF_ERR_DTYPE, "dtype %d", dtype);
+  // whole tiles first, the remaining rows (and unaligned calls) one thread per row
+  const int64_t done = vmf3_log_prob_ref_tiles(logp ? loc : nullptr, scale, logp ? x : nullptr, logp, lognorm, n, dtype,
+                                               (hipStream_t)stream);
+  if (done < n) {
+    const int64_t es = dtype == VMF_F32 ? 4 : 8, rest = n - done;
+    const auto at = [&](const void* q, int64_t per_row) {
+      return q ? (const void*)((const char*)q + done * per_row * es) : nullptr;
+    };
+    int grid = vmf_grid_for(rest, 256);
+    VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(vmf3_log_prob_ref_kernel<T>, dim3(grid), dim3(256), 0,
+                                                 (hipStream_t)stream, (const T*)at(loc, 3), (const T*)at(scale, 1),
+                                                 (const T*)at(x, 3), (T*)at(logp, 1), (T*)at(lognorm, 1), rest));
+  }
   return vmf_check_launch("vmf3_log_prob_ref");
 }
 
@@ -529,22 +538,14 @@ __global__ __launch_bounds__(256) void vmf3_log_prob_ref_bwd_kernel(const T* __r
     const T k = scale[i], g = gl[i];
     T r[3] = {loc[3 * i], loc[3 * i + 1], loc[3 * i + 2]};
     T xv[3] = {x[3 * i], x[3 * i + 1], x[3 * i + 2]};
-    T l[3], nn;
-    v3_normalise_loc<T>(r, l, &nn);
-    const T dot = l[0] * xv[0] + l[1] * xv[1] + l[2] * xv[2];
-    if (dscale) {
-      // d/dk [k dot - (log k - log 4pi - log(sinh k + 1e-10))] = dot - 1/k + cosh k / (sinh k + 1e-10)
-      const T sh = M<T>::sinh(k) + (T)1e-10;
-      dscale[i] = g * (dot - (T)1 / k + M<T>::cosh(k) / sh);
-    }
+    T dl[3], dk, dxr[3];
+    v3_log_prob_ref_bwd_row<T>(r, k, xv, g, dl, &dk, dxr);
+    if (dscale) dscale[i] = dk;
     if (dx) {
-      dx[3 * i] = g * k * l[0]; dx[3 * i + 1] = g * k * l[1]; dx[3 * i + 2] = g * k * l[2];
+      dx[3 * i] = dxr[0]; dx[3 * i + 1] = dxr[1]; dx[3 * i + 2] = dxr[2];
     }
     if (dloc) {
-      T dl[3] = {g * k * xv[0], g * k * xv[1], g * k * xv[2]};
-      const T nden = nn + (T)1e-5;
-      const T rdl = r[0] * dl[0] + r[1] * dl[1] + r[2] * dl[2];
-      for (int c = 0; c < 3; ++c) dloc[3 * i + c] = dl[c] / nden - r[c] * rdl / (nn * nden * nden);
+      dloc[3 * i] = dl[0]; dloc[3 * i + 1] = dl[1]; dloc[3 * i + 2] = dl[2];
     }
   }
 }
@@ -555,10 +556,19 @@ extern "C" int vmf3_log_prob_ref_bwd(const void* loc, const void* scale, const v
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(loc && scale && x && gl, VMF_ERR_BAD_ARG, "vmf3_log_prob_ref_bwd: null pointer");
-  int grid = vmf_grid_for(n, 256);
-  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(vmf3_log_prob_ref_bwd_kernel<T>, dim3(grid), dim3(256), 0,
-                                               (hipStream_t)stream, (const T*)loc, (const T*)scale, (const T*)x,
-                                               (const T*)gl, (T*)dloc, (T*)dscale, (T*)dx, n));
+  VMF_REQUIRE(dtype == VMF_F32 || dtype == VMF_F64, VMF_ERR_DTYPE, "dtype %d", dtype);
+  const int64_t done = vmf3_log_prob_ref_bwd_tiles(loc, scale, x, gl, dloc, dscale, dx, n, dtype, (hipStream_t)stream);
+  if (done < n) {
+    const int64_t es = dtype == VMF_F32 ? 4 : 8, rest = n - done;
+    const auto at = [&](const void* q, int64_t per_row) {
+      return q ? (const void*)((const char*)q + done * per_row * es) : nullptr;
+    };
+    int grid = vmf_grid_for(rest, 256);
+    VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(vmf3_log_prob_ref_bwd_kernel<T>, dim3(grid), dim3(256), 0,
+                                                 (hipStream_t)stream, (const T*)at(loc, 3), (const T*)at(scale, 1),
+                                                 (const T*)at(x, 3), (const T*)at(gl, 1), (T*)at(dloc, 3),
+                                                 (T*)at(dscale, 1), (T*)at(dx, 3), rest));
+  }
   return vmf_check_launch("vmf3_log_prob_ref_bwd");
 }
 

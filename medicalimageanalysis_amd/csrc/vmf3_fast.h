@@ -20,6 +20,12 @@ int vmf3_bwd_rows(const V3Call& c, int64_t n);
 int vmf3_fwd_outer(const V3Call& c, int64_t n_i, int64_t n_j);
 int vmf3_bwd_outer(const V3Call& c, int64_t n_i, int64_t n_j, void* workspace, int64_t workspace_bytes);
 int64_t vmf3_bwd_outer_workspace_bytes(int64_t n_i, int64_t n_j, int dtype);
+// CNN_experiment/von_mises_fisher.py:88-108 on whole tiles of 256 rows (every pointer given 16-byte aligned): the
+// number of leading rows taken; the caller's thread-per-row kernel takes the rest
+int64_t vmf3_log_prob_ref_tiles(const void* loc, const void* scale, const void* x, void* logp, void* lognorm, int64_t n,
+                                int dtype, hipStream_t stream);
+int64_t vmf3_log_prob_ref_bwd_tiles(const void* loc, const void* scale, const void* x, const void* gl, void* dloc,
+                                    void* dscale, void* dx, int64_t n, int dtype, hipStream_t stream);
 
 // Noise of index i comes from ONE call, Philox(i, slot 0) = (x, y, z, w) -- u01 reads the upper 23 bits of a word, so
 // five uniforms fit into the four words without sharing a bit:

@@ -582,3 +582,106 @@ int vmf3_bwd_outer(const V3Call& c, int64_t n_i, int64_t n_j, void* workspace, i
   else launch_outer_bwd<double, M<double>>(c, n_i, n_j, ntj, nti, rpw, workspace);
   return VMF_OK;
 }
+
+// ---- (3) log_prob with the reference's sign, whole tiles -----------------------------------------------------------------
+// The thread-per-row kernels read and write (n, 3) arrays as 4-byte elements 12 bytes apart from lane to lane -- six to
+// fifteen such accesses per row, and the address unit's time for them is those kernels' time.  Here every (256, 3)
+// operand moves as coalesced 16-byte accesses and is re-dealt through the wave's LDS slab (lane l owns rows 4 l ..
+// 4 l + 3), per-row scalars as one 16-byte access per lane.  Same row functions, same bits.
+template <typename T>
+__global__ __launch_bounds__(256) void vmf3_log_prob_ref_tile_kernel(const T* __restrict__ loc,
+                                                                     const T* __restrict__ scale,
+                                                                     const T* __restrict__ x, T* __restrict__ logp,
+                                                                     T* __restrict__ lognorm, int64_t ntiles) {
+  constexpr int U = v3_units<T>();
+  __shared__ u32x4 s_slab[4][64 * U];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t t = (int64_t)blockIdx.x * 4 + wave;
+  if (t >= ntiles) return;  // wave-uniform; no workgroup barrier
+  const int64_t row0 = t * V3_TILE_ROWS;
+  u32x4* const slab = s_slab[wave];
+  T k[4], lp[4], ln[4];
+  quad_load<T>(scale + row0, lane, k);
+  if (logp) {
+    u32x4 fl[U], fx[U];
+    T r[12], xv[12];
+    tile_fetch<T>(loc + 3 * row0, lane, fl);
+    tile_fetch<T>(x + 3 * row0, lane, fx);
+    tile_deal_in<T>(slab, lane, fl, r);
+    tile_deal_in<T>(slab, lane, fx, xv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lp[j] = v3_log_prob_ref_row<T>(r + 3 * j, k[j], xv + 3 * j, &ln[j]);
+    quad_store<T>(logp + row0, lane, lp);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v3_log_norm_ref<T>(k[j], &ln[j], (T*)nullptr);
+  }
+  if (lognorm) quad_store<T>(lognorm + row0, lane, ln);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vmf3_log_prob_ref_bwd_tile_kernel(const T* __restrict__ loc,
+                                                                         const T* __restrict__ scale,
+                                                                         const T* __restrict__ x,
+                                                                         const T* __restrict__ gl, T* __restrict__ dloc,
+                                                                         T* __restrict__ dscale, T* __restrict__ dx,
+                                                                         int64_t ntiles) {
+  constexpr int U = v3_units<T>();
+  __shared__ u32x4 s_slab[4][64 * U];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t t = (int64_t)blockIdx.x * 4 + wave;
+  if (t >= ntiles) return;
+  const int64_t row0 = t * V3_TILE_ROWS;
+  u32x4* const slab = s_slab[wave];
+  u32x4 fl[U], fx[U];
+  T r[12], xv[12], k[4], g[4], dl[12], dxr[12], dk[4];
+  tile_fetch<T>(loc + 3 * row0, lane, fl);
+  tile_fetch<T>(x + 3 * row0, lane, fx);
+  quad_load<T>(scale + row0, lane, k);
+  quad_load<T>(gl + row0, lane, g);
+  tile_deal_in<T>(slab, lane, fl, r);
+  tile_deal_in<T>(slab, lane, fx, xv);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    v3_log_prob_ref_bwd_row<T>(r + 3 * j, k[j], xv + 3 * j, g[j], dl + 3 * j, &dk[j], dxr + 3 * j);
+  if (dloc) tile_store<T>(dloc + 3 * row0, slab, lane, dl);
+  if (dx) tile_store<T>(dx + 3 * row0, slab, lane, dxr);
+  if (dscale) quad_store<T>(dscale + row0, lane, dk);
+}
+
+static bool lp_tiles_ok(int64_t n, std::initializer_list<const void*> ptrs) {
+  if (n < V3_TILE_ROWS || (n / V3_TILE_ROWS + 3) / 4 >= 0x7fffffff) return false;
+  for (const void* q : ptrs)
+    if (!v3_aligned16(q)) return false;  // (a null pointer counts as aligned)
+  return true;
+}
+
+int64_t vmf3_log_prob_ref_tiles(const void* loc, const void* scale, const void* x, void* logp, void* lognorm, int64_t n,
+                                int dtype, hipStream_t stream) {
+  if (!lp_tiles_ok(n, {loc, scale, x, logp, lognorm})) return 0;
+  const int64_t ntiles = n / V3_TILE_ROWS;
+  const dim3 grid((unsigned)((ntiles + 3) / 4)), block(256);
+  if (dtype == VMF_F32)
+    hipLaunchKernelGGL(vmf3_log_prob_ref_tile_kernel<float>, grid, block, 0, stream, (const float*)loc,
+                       (const float*)scale, (const float*)x, (float*)logp, (float*)lognorm, ntiles);
+  else
+    hipLaunchKernelGGL(vmf3_log_prob_ref_tile_kernel<double>, grid, block, 0, stream, (const double*)loc,
+                       (const double*)scale, (const double*)x, (double*)logp, (double*)lognorm, ntiles);
+  return ntiles * V3_TILE_ROWS;
+}
+
+int64_t vmf3_log_prob_ref_bwd_tiles(const void* loc, const void* scale, const void* x, const void* gl, void* dloc,
+                                    void* dscale, void* dx, int64_t n, int dtype, hipStream_t stream) {
+  if (!lp_tiles_ok(n, {loc, scale, x, gl, dloc, dscale, dx})) return 0;
+  const int64_t ntiles = n / V3_TILE_ROWS;
+  const dim3 grid((unsigned)((ntiles + 3) / 4)), block(256);
+  if (dtype == VMF_F32)
+    hipLaunchKernelGGL(vmf3_log_prob_ref_bwd_tile_kernel<float>, grid, block, 0, stream, (const float*)loc,
+                       (const float*)scale, (const float*)x, (const float*)gl, (float*)dloc, (float*)dscale, (float*)dx,
+                       ntiles);
+  else
+    hipLaunchKernelGGL(vmf3_log_prob_ref_bwd_tile_kernel<double>, grid, block, 0, stream, (const double*)loc,
+                       (const double*)scale, (const double*)x, (const double*)gl, (double*)dloc, (double*)dscale,
+                       (double*)dx, ntiles);
+  return ntiles * V3_TILE_ROWS;
+}

@@ -261,6 +261,70 @@ VMF_HD void fast_sinh_cosh(float k, float* sh, float* ch) {
   }
 }
 
+// ---- CNN_experiment/von_mises_fisher.py:92-108: log_prob with the reference's sign, one row ----------------------
+// log k - log 4 pi - log(sinh k + 1e-10) and (for the gradient) cosh k / (sinh k + 1e-10).  Double precision through
+// the library; single precision through the hardware logarithm and fast_sinh_cosh, which keeps sinhf's overflow point
+// float for float (inf beyond 89.415985: the reference's -inf normaliser and NaN gradient there).  Both kernels that
+// evaluate rows (whole tiles, thread per row) call these, so a row's value does not depend on the layout.
+// (every rounding fixed -- no contraction left to the compiler -- so that the inlined copies agree)
+template <typename T>
+VMF_HD void v3_log_norm_ref(T k, T* ln, T* coth_eps) {
+#pragma clang fp contract(off)
+  const T sh = M<T>::sinh(k) + (T)1e-10;
+  *ln = M<T>::log(k) - (T)2.5310242469692907 /* log(4 pi) */ - M<T>::log(sh);
+  if (coth_eps) *coth_eps = M<T>::cosh(k) / sh;
+}
+template <>
+VMF_HD void v3_log_norm_ref<float>(float k, float* ln, float* coth_eps) {
+#pragma clang fp contract(off)
+  if (!(k > 0.0f && k < INFINITY)) {  // zero, negative, NaN, inf: whatever the library makes of them
+    const float sh = ::sinhf(k) + 1e-10f;
+    *ln = ::logf(k) - 2.5310242469692907f - ::logf(sh);
+    if (coth_eps) *coth_eps = ::coshf(k) / sh;
+    return;
+  }
+  float sh, ch;
+  fast_sinh_cosh(k, &sh, &ch);
+  sh += 1e-10f;
+  *ln = fast_log(k) - 2.5310242469692907f - fast_log(sh);
+  if (coth_eps) *coth_eps = ch * fast_rcp(sh);
+}
+template <typename T>
+VMF_HD void v3_normalise_loc_fixed(const T r[3], T l[3], T* n_out) {  // v3_normalise_loc with its roundings fixed
+#pragma clang fp contract(off)
+  const T n = M<T>::sqrt((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+  const T den = n + (T)1e-5;
+  l[0] = r[0] / den; l[1] = r[1] / den; l[2] = r[2] / den;
+  *n_out = n;
+}
+template <typename T>
+VMF_HD T v3_log_prob_ref_row(const T r[3], T k, const T x[3], T* ln_out) {
+#pragma clang fp contract(off)
+  T l[3], nn, ln;
+  v3_normalise_loc_fixed<T>(r, l, &nn);
+  v3_log_norm_ref<T>(k, &ln, (T*)nullptr);
+  if (ln_out) *ln_out = ln;
+  const T dot = (l[0] * x[0] + l[1] * x[1]) + l[2] * x[2];
+  return k * dot - ln;  // :92-95 (the reference subtracts)
+}
+// gradients of g * log_prob with respect to the raw loc row, kappa and x (what autograd derives from :92-108)
+template <typename T>
+VMF_HD void v3_log_prob_ref_bwd_row(const T r[3], T k, const T xv[3], T g, T dloc[3], T* dscale, T dx[3]) {
+#pragma clang fp contract(off)
+  T l[3], nn;
+  v3_normalise_loc_fixed<T>(r, l, &nn);
+  const T dot = (l[0] * xv[0] + l[1] * xv[1]) + l[2] * xv[2];
+  T ln, ce;
+  v3_log_norm_ref<T>(k, &ln, &ce);
+  // d/dk [k dot - (log k - log 4pi - log(sinh k + 1e-10))] = dot - 1/k + cosh k / (sinh k + 1e-10)
+  *dscale = g * (dot - (T)1 / k + ce);
+  dx[0] = g * k * l[0]; dx[1] = g * k * l[1]; dx[2] = g * k * l[2];
+  const T dl[3] = {g * k * xv[0], g * k * xv[1], g * k * xv[2]};
+  const T nden = nn + (T)1e-5;
+  const T rdl = (r[0] * dl[0] + r[1] * dl[1]) + r[2] * dl[2];
+  for (int c = 0; c < 3; ++c) dloc[c] = dl[c] / nden - r[c] * rdl / (nn * nden * nden);
+}
+
 // Unrolled on purpose (unlike the double-precision sums): single-precision coefficients are free 32-bit literals of
 // the fma, so a term costs two instructions instead of a scalar load and the loop bookkeeping.
 template <int n>

@@ -1554,6 +1554,51 @@ def test_general_log_prob_entropy_kl(oracle, tag, m):
         np.testing.assert_allclose(N(tm.grad), kappa[:, None] * x, rtol=1e-12)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_vmf3_log_prob_ref_tile_kernels_and_row_kernels_give_the_same_bits(dt):
+    """CNN_experiment log_prob: aligned calls take whole tiles of 256 rows (plus a thread-per-row tail), views that start
+    one element into their buffer the thread-per-row kernels throughout: same bits, forward and backward, including
+    the concentrations around sinh's overflow point"""
+    lib, sp = _lib.lib(), _lib.stream_ptr(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(12)
+    n = 256 * 9 + 77
+    loc = torch.randn(n, 3, device=DEV, generator=gen, dtype=dt)
+    x = torch.nn.functional.normalize(torch.randn(n, 3, device=DEV, generator=gen, dtype=dt), dim=-1)
+    k = torch.exp(torch.rand(n, device=DEV, generator=gen, dtype=dt) * 9 - 3)
+    k[:4] = torch.tensor([89.415985, 89.41599, 1e-4, 700.0], device=DEV, dtype=dt)
+    gl = torch.randn(n, device=DEV, generator=gen, dtype=dt)
+
+    def off(t):
+        buf = torch.empty(t.numel() + 1, device=DEV, dtype=dt)
+        v = buf[1:].view(t.shape)
+        v.copy_(t)
+        return v
+
+    def run(loc_, x_, k_, gl_, mk):
+        lp, ln = mk(n), mk(n)
+        _lib.check(lib.vmf3_log_prob_ref(_lib.ptr(loc_), _lib.ptr(k_), _lib.ptr(x_), _lib.ptr(lp), _lib.ptr(ln), n,
+                                         _lib.dtype_code(loc_), sp), "vmf3_log_prob_ref")
+        dl, dk, dx = mk(n, 3), mk(n), mk(n, 3)
+        _lib.check(lib.vmf3_log_prob_ref_bwd(_lib.ptr(loc_), _lib.ptr(k_), _lib.ptr(x_), _lib.ptr(gl_), _lib.ptr(dl),
+                                             _lib.ptr(dk), _lib.ptr(dx), n, _lib.dtype_code(loc_), sp), "vmf3_log_prob_ref_bwd")
+        return [t.clone() for t in (lp, ln, dl, dk, dx)]
+
+    aligned = run(loc, x, k, gl, lambda *sh: torch.full(sh, float("nan"), device=DEV, dtype=dt))
+    rows = run(off(loc), off(x), off(k), off(gl), lambda *sh: off(torch.full(sh, float("nan"), device=DEV, dtype=dt)))
+    for a, b in zip(aligned, rows):
+        assert torch.equal(a.isnan(), b.isnan())
+        assert torch.equal(torch.nan_to_num(a, nan=0.0), torch.nan_to_num(b, nan=0.0))
+    # against the formula in double precision, where it is finite
+    l64 = loc.double() / (loc.double().norm(dim=-1, keepdim=True) + 1e-5)
+    k64 = k.double()
+    ln64 = torch.log(k64) - np.log(4 * np.pi) - torch.log(torch.sinh(k64) + 1e-10)
+    ref = k64 * (l64 * x.double()).sum(-1) - ln64
+    fin = torch.isfinite(ref) & (k64 < 80)
+    tol = 1e-12 if dt == torch.float64 else 3e-6
+    err = ((aligned[0].double() - ref).abs() / (1 + ref.abs()))[fin]
+    assert float(err.max()) < tol, float(err.max())
+
+
 def test_gradients_reach_kappa_through_lognorm_and_mean():
     """CNN_experiment/von_mises_fisher.py:97-108 is differentiable in kappa, and so is the general-m mean A_m(kappa) mu"""
     k = (torch.rand(50, device=DEV, dtype=torch.float64) * 30 + 0.5).requires_grad_()
