@@ -76,10 +76,14 @@ constexpr uint32_t SLOT_GAUSS = 0x10000u;
 // 1.16 / 1.25 / 1.26 / 1.28; m = 64 2.35 / 2.21 / 2.20 / 2.36 / 2.33 / 2.28; m = 128 - / 2.25 / 2.23 / 2.36 / 2.32 /
 // 2.30; m = 256 flat (2.30 .. 2.35); m = 512 - / - / 4.65 / 4.63 / 4.42 / 4.86; m = 1024 - / 5.82 / 4.49 / 4.43 / 4.86 /
 // 5.39.  Hence 4, except the two-pass shape (16) and the four- and eight-pass shapes (8).
-#ifndef VMF_LP_STEPS
-#define VMF_LP_STEPS 16
+// log_prob, lane-group kernel: steps (of 64 / LPR rows) per wave.  With non-temporal stores of d mu and d x, measured on
+// 2^24 / 2^23 / 2^22 / 2^21 / 2^19 rows of 8 / 16 / 64 / 128 / 512 floats against 16 steps and plain stores:
+// forward 2 steps -6 / -5 / -4 / -5 / -6 %; backward 4 steps -12 / -14 %, 1 step -15 / -15 / -16 % (the wide three)
+#ifdef VMF_LP_STEPS
+constexpr int lp_steps(bool, int) { return VMF_LP_STEPS; }
+#else
+constexpr int lp_steps(bool bwd, int lpr) { return bwd ? (lpr >= 8 ? 1 : 4) : 2; }
 #endif
-constexpr int LP_STEPS = VMF_LP_STEPS;
 #ifdef VMF_BWD_STEPS
 constexpr int bwd_steps(int, int) { return VMF_BWD_STEPS; }
 #else
@@ -144,10 +148,17 @@ __device__ __forceinline__ void load4(const T* __restrict__ rowp, int e0, int m,
     for (int i = 0; i < 4; ++i) out[i] = (e0 + i < m) ? rowp[e0 + i] : (T)0;
   }
 }
-template <typename T, bool VEC>
+template <typename T, bool VEC, bool STREAM = false>
 __device__ __forceinline__ void store4(T* __restrict__ rowp, int e0, int m, const T in[4]) {
   if (VEC) {
     if (e0 < m) {
+      if constexpr (STREAM && sizeof(T) == 4) {  // written once, read by a later kernel: non-temporal 128-bit store
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f v;
+        v.x = in[0]; v.y = in[1]; v.z = in[2]; v.w = in[3];
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(rowp + e0));
+        return;
+      }
       Vec4<T> v;
       v.v[0] = in[0]; v.v[1] = in[1]; v.v[2] = in[2]; v.v[3] = in[3];
       *reinterpret_cast<Vec4<T>*>(rowp + e0) = v;
@@ -1840,6 +1851,7 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_log_prob_dot_kernel(LogProbPar
   const int m = p.m;
   const int64_t n_steps = (p.n + RPI - 1) / RPI;
   const int64_t wave_id = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  constexpr int LP_STEPS = lp_steps(BWD, LPR);
   const int64_t step_end = (wave_id + 1) * LP_STEPS < n_steps ? (wave_id + 1) * LP_STEPS : n_steps;
   for (int64_t step = wave_id * LP_STEPS; step < step_end; ++step) {  // wave-uniform
     const int64_t r = step * RPI + grp;
@@ -1870,8 +1882,8 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_log_prob_dot_kernel(LogProbPar
         T a[4], b[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { a[i] = gk * x[j][i]; b[i] = gk * mu[j][i]; }
-        if (p.dmu) store4<T, VEC>(p.dmu + row * (int64_t)m, 4 * chunk, m, a);
-        if (p.dx) store4<T, VEC>(p.dx + row * (int64_t)m, 4 * chunk, m, b);
+        if (p.dmu) store4<T, VEC, true>(p.dmu + row * (int64_t)m, 4 * chunk, m, a);
+        if (p.dx) store4<T, VEC, true>(p.dx + row * (int64_t)m, 4 * chunk, m, b);
       }
       if (p.dkappa && sub == 0) p.dkappa[row] += p.gl[row] * dot;  // -g A_m(kappa) was stored by pass 1
     }
@@ -1887,6 +1899,192 @@ static void launch_log_prob(const LogProbParams<T>& p, int grid, hipStream_t s) 
 #undef VMF_CALL
 }
 
+// log_prob for the narrow fp32 widths (3 to 32), dense rows: ONE lane owns a row, as in the rowlane sampler kernels.  The
+// tile's mu, then its x, move from HBM as flat arrays of 16-byte units through one wave-private LDS slab; the Bessel term
+// of the row is evaluated in the lane that owns it (forward: log C_m(kappa) in single precision; backward: -g A_m(kappa)
+// in double precision through the coefficient tables), so each direction is ONE launch and the double arithmetic of one
+// wave hides behind the loads of the others.  d mu and d x go back through the slab.  Measured, 2^24 rows of 10 floats:
+// forward 0.468 -> 0.233 ms, backward 0.886 -> 0.511 (two passes, lane groups with guarded scalar accesses before);
+// 2^24 rows of 8: 0.285 -> 0.188 and 0.761 -> 0.495; 2^23 rows of 16: 0.227 -> 0.185 and 0.564 -> 0.430.
+#ifndef VMF_LPR_FUSE_A
+#define VMF_LPR_FUSE_A 1
+#endif
+template <int M, bool BWD>
+__global__ __launch_bounds__(WAVES * 64) void vmf_log_prob_rowlane_kernel(LogProbParams<float> p, float lc_v, float lc_lg,
+                                                                          float lc_c0, VmfDim dim, VmfDimTab tab) {
+  using T = float;
+  constexpr int RL_TILE = rl_tile(M);
+  constexpr int UNITS = RL_TILE * M / 4;
+  constexpr int UPL = (UNITS + 63) / 64;
+  constexpr int SUBS = RL_TILE / 64;
+  // a lane reads its row from the slab in 16-byte pieces when the width allows; rows of 8, 16 or 24 floats would then
+  // start 8, 4 or 8 to a bank group, so those are kept 16 bytes apart (a pitch of an odd number of 16-byte units)
+  constexpr int PITCH = M % 8 == 0 ? M + 4 : M;
+  constexpr int UPR = M / 4;  // (used only when M % 8 == 0)
+  __shared__ __align__(16) T s_rows[WAVES][RL_TILE * PITCH];
+  auto unit_at = [](int q) { return M % 8 == 0 ? q + q / UPR : q; };
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* const srow = s_rows[wave];
+  const int64_t tile0 = ((int64_t)blockIdx.x * WAVES + wave) * RL_TILE;  // wave-uniform
+  const int64_t left = p.n - tile0;
+  if (left <= 0) return;  // the kernel has no workgroup barrier
+  const int ntile = left < RL_TILE ? (int)left : RL_TILE;
+  const bool full = ntile == RL_TILE;
+  const T* const mu_t = p.mu + tile0 * M;
+  const T* const x_t = p.x + tile0 * M;
+  T kap[SUBS], gl[SUBS];
+#pragma unroll
+  for (int sub = 0; sub < SUBS; ++sub) {
+    const int r = sub * 64 + lane;
+    kap[sub] = r < ntile ? p.kappa[(tile0 + r) * p.kappa_stride] : (T)1;
+    gl[sub] = BWD && r < ntile ? p.gl[tile0 + r] : (T)0;
+  }
+  u32x4 st_mu[UPL], st_x[UPL];
+  if (full) {
+#pragma unroll
+    for (int s = 0; s < UPL; ++s) {
+      const int q = lane + 64 * s;
+      if (UNITS % 64 == 0 || q < UNITS) {
+        st_mu[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(mu_t) + q);
+        st_x[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x_t) + q);
+      }
+    }
+  }
+  auto park = [&](const u32x4 (&st)[UPL], const T* src) {
+    if (full) {
+#pragma unroll
+      for (int s = 0; s < UPL; ++s) {
+        const int q = lane + 64 * s;
+        if (UNITS % 64 == 0 || q < UNITS) reinterpret_cast<u32x4*>(srow)[unit_at(q)] = st[s];
+      }
+    } else {
+      for (int e = lane; e < ntile * M; e += 64) srow[(e / M) * PITCH + e % M] = src[e];
+    }
+    wave_lds_sync();
+  };
+  auto flush = [&](T* dst) {
+    wave_lds_sync();
+    if (full) {
+#pragma unroll
+      for (int s = 0; s < UPL; ++s) {
+        const int q = lane + 64 * s;
+        if (UNITS % 64 == 0 || q < UNITS) {
+          f32x4 v;
+          const u32x4 raw = reinterpret_cast<const u32x4*>(srow)[unit_at(q)];
+          __builtin_memcpy(&v, &raw, 16);
+          store_nt(v, dst + 4 * q);
+        }
+      }
+    } else {
+      for (int e = lane; e < ntile * M; e += 64) dst[e] = srow[(e / M) * PITCH + e % M];
+    }
+    wave_lds_sync();
+  };
+  auto row_get = [&](int r, T (&dst)[M]) {
+    if (M % 4 == 0) {
+#pragma unroll
+      for (int e = 0; e < M; e += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(srow + r * PITCH + e);
+        dst[e] = v.x; dst[e + 1] = v.y; dst[e + 2] = v.z; dst[e + 3] = v.w;
+      }
+    } else if (M % 2 == 0) {
+#pragma unroll
+      for (int e = 0; e < M; e += 2) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(srow + r * PITCH + e);
+        dst[e] = v.x; dst[e + 1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < M; ++e) dst[e] = srow[r * PITCH + e];
+    }
+  };
+  auto row_put = [&](int r, const T (&src)[M], T scale) {
+    if (M % 4 == 0) {
+#pragma unroll
+      for (int e = 0; e < M; e += 4) {
+        f32x4 v;
+        v.x = scale * src[e]; v.y = scale * src[e + 1]; v.z = scale * src[e + 2]; v.w = scale * src[e + 3];
+        *reinterpret_cast<f32x4*>(srow + r * PITCH + e) = v;
+      }
+    } else if (M % 2 == 0) {
+#pragma unroll
+      for (int e = 0; e < M; e += 2) {
+        f32x2 v;
+        v.x = scale * src[e]; v.y = scale * src[e + 1];
+        *reinterpret_cast<f32x2*>(srow + r * PITCH + e) = v;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < M; ++e) srow[r * PITCH + e] = scale * src[e];
+    }
+  };
+  T mu[SUBS][M];
+  park(st_mu, mu_t);
+#pragma unroll
+  for (int sub = 0; sub < SUBS; ++sub) {
+    const int r = sub * 64 + lane;
+    if (r < ntile) row_get(r, mu[sub]);
+  }
+  wave_lds_sync();
+  park(st_x, x_t);
+#pragma unroll
+  for (int sub = 0; sub < SUBS; ++sub) {
+    const int r = sub * 64 + lane;
+    if (r < ntile) {
+      const int64_t row = tile0 + r;
+      T x[M];
+      row_get(r, x);
+      T dot = 0;
+#pragma unroll
+      for (int e = 0; e < M; ++e) dot += mu[sub][e] * x[e];
+      if (!BWD) {
+        p.logp[row] = vmf_log_norm_f32v(lc_v, lc_lg, lc_c0, kap[sub]) + kap[sub] * dot;
+      } else {
+        if (p.dkappa) {
+          // -g A_m(kappa) in double precision, rounded, then + g <mu, x>: the two-pass kernels' bits
+          const T first = VMF_LPR_FUSE_A ? (T)(-(double)gl[sub] * vmf_mean_resultant_tab(dim, tab, (double)kap[sub]))
+                                         : p.dkappa[row];
+          p.dkappa[row] = first + gl[sub] * dot;
+        }
+        if (p.dmu) row_put(r, x, gl[sub] * kap[sub]);
+      }
+    }
+  }
+  if (BWD) {
+    T* const dmu_t = p.dmu ? p.dmu + tile0 * M : nullptr;
+    T* const dx_t = p.dx ? p.dx + tile0 * M : nullptr;
+    if (dmu_t) flush(dmu_t);
+    if (dx_t) {
+      if (!dmu_t) wave_lds_sync();
+#pragma unroll
+      for (int sub = 0; sub < SUBS; ++sub) {
+        const int r = sub * 64 + lane;
+        if (r < ntile) row_put(r, mu[sub], gl[sub] * kap[sub]);
+      }
+      flush(dx_t);
+    }
+  }
+}
+
+static bool log_prob_rowlane_ok(int m) { return m >= 3 && m <= 32; }
+template <bool BWD>
+static void launch_log_prob_rowlane(const LogProbParams<float>& p, const VmfDim& dim, hipStream_t s) {
+  const int64_t tiles = (p.n + rl_tile(p.m) - 1) / rl_tile(p.m);
+  const dim3 grid((unsigned)((tiles + WAVES - 1) / WAVES)), block(WAVES * 64);
+  const float v = (float)dim.v, lg = (float)dim.lg_v1, c0 = (float)dim.half_m_log2pi;
+  const VmfDimTab tab = BWD ? make_vmf_dim_tab(dim) : VmfDimTab{};
+  switch (p.m) {
+#define VMF_RL(MM) \
+  case MM: hipLaunchKernelGGL((vmf_log_prob_rowlane_kernel<MM, BWD>), grid, block, 0, s, p, v, lg, c0, dim, tab); break
+    VMF_RL(3); VMF_RL(4); VMF_RL(5); VMF_RL(6); VMF_RL(7); VMF_RL(8); VMF_RL(9); VMF_RL(10); VMF_RL(11); VMF_RL(12);
+    VMF_RL(13); VMF_RL(14); VMF_RL(15); VMF_RL(16); VMF_RL(17); VMF_RL(18); VMF_RL(19); VMF_RL(20); VMF_RL(21); VMF_RL(22);
+    VMF_RL(23); VMF_RL(24); VMF_RL(25); VMF_RL(26); VMF_RL(27); VMF_RL(28); VMF_RL(29); VMF_RL(30); VMF_RL(31);
+    VMF_RL(32);
+#undef VMF_RL
+    default: break;
+  }
+}
+
 template <typename T, bool BWD>
 static int log_prob_t(const void* mu, int64_t mu_stride, const void* kappa, int64_t kappa_stride, const void* x,
                       const void* gl, void* logp, void* dmu, void* dx, void* dkappa, int64_t n, int m, hipStream_t s) {
@@ -1896,16 +2094,30 @@ static int log_prob_t(const void* mu, int64_t mu_stride, const void* kappa, int6
   p.n = n; p.mu_stride = mu_stride; p.kappa_stride = (int)kappa_stride; p.m = m;
   VmfDim dim = make_vmf_dim(m);
   T* rowterm = BWD ? (T*)dkappa : (T*)logp;
-  if (rowterm)
+  bool rowlane = false;
+  if constexpr (sizeof(T) == 4) {
+    rowlane = log_prob_rowlane_ok(m) && mu_stride == m && aligned16(mu) && aligned16(x) && (!dmu || aligned16(dmu)) &&
+              (!dx || aligned16(dx));
+    if (rowlane)
+      VMF_REQUIRE((n + rl_tile(m) - 1) / rl_tile(m) / WAVES < 0x7fffffff, VMF_ERR_UNSUPPORTED,
+                  "n=%lld rows need more than 2^31 workgroups", (long long)n);
+  }
+  if (rowterm && !(rowlane && (!BWD || VMF_LPR_FUSE_A)))
     hipLaunchKernelGGL((vmf_log_prob_rowterm_kernel<T, BWD>), dim3(vmf_grid_for(n, 256)), dim3(256), 0, s, (const T*)kappa,
                        kappa_stride, (const T*)gl, rowterm, n, dim, make_vmf_dim_tab(dim));
+  if constexpr (sizeof(T) == 4) {
+    if (rowlane) {
+      launch_log_prob_rowlane<BWD>(p, dim, s);
+      return VMF_OK;
+    }
+  }
   const bool vec = (m % 4 == 0) && (mu_stride % 4 == 0) && aligned16(mu) && aligned16(x) && (!dmu || aligned16(dmu)) &&
                    (!dx || aligned16(dx));
   const int chunks = (m + 3) / 4;
   int lpr, kpasses;
   pick_shape(chunks, &lpr, &kpasses);
   const int64_t steps = (n + (64 / lpr) - 1) / (64 / lpr);
-  const int64_t waves = (steps + LP_STEPS - 1) / LP_STEPS;
+  const int64_t waves = (steps + lp_steps(BWD, lpr) - 1) / lp_steps(BWD, lpr);
   int64_t gb = (waves + WAVES - 1) / WAVES;
   VMF_REQUIRE(gb <= 0x7fffffff, VMF_ERR_UNSUPPORTED, "n=%lld rows need more than 2^31 workgroups", (long long)n);
   const int grid = (int)(gb < 1 ? 1 : gb);

@@ -1554,6 +1554,59 @@ def test_general_log_prob_entropy_kl(oracle, tag, m):
         np.testing.assert_allclose(N(tm.grad), kappa[:, None] * x, rtol=1e-12)
 
 
+@pytest.mark.parametrize("m", list(range(3, 34)) + [64])
+def test_general_log_prob_lane_per_row_kernel_against_the_lane_group_kernel_and_fp64(m):
+    """Dense fp32 rows of up to 32 floats take a lane-per-row kernel (log C_m, or A_m, evaluated in the lane: one
+    launch); a row pitch wider than m sends the same rows through the lane-group kernel (so does m = 64 either way).  Both against the same call
+    in double precision, forward and backward, with full tiles, a ragged last tile, and absent gradient outputs."""
+    lib, sp = _lib.lib(), _lib.stream_ptr(DEV)
+    n = 5 * 384 + 77
+    g = torch.Generator(device="cpu").manual_seed(900 + m)
+    mu = torch.nn.functional.normalize(torch.randn(n, m, generator=g, dtype=torch.float64), dim=-1).to(DEV)
+    x = torch.nn.functional.normalize(torch.randn(n, m, generator=g, dtype=torch.float64), dim=-1).to(DEV)
+    kappa = torch.exp(torch.rand(n, generator=g, dtype=torch.float64) * np.log(1e4) + np.log(0.1)).to(DEV)
+    gl = torch.randn(n, generator=g, dtype=torch.float64).to(DEV)
+
+    def run(dt, pitch):
+        code = _lib.dtype_code(torch.empty(0, dtype=dt))
+        mub = torch.zeros(n, pitch, device=DEV, dtype=dt)
+        mub[:, :m] = mu.to(dt)
+        xc, kc, glc = x.to(dt).contiguous(), kappa.to(dt).contiguous(), gl.to(dt).contiguous()
+        lp = torch.full((n,), float("nan"), device=DEV, dtype=dt)
+        rc = lib.vmf_log_prob_fwd(_lib.ptr(mub), pitch, _lib.ptr(kc), 1, _lib.ptr(xc), _lib.ptr(lp), n, m, code, sp)
+        _lib.check(rc, "vmf_log_prob")
+        dmu = torch.full((n, m), float("nan"), device=DEV, dtype=dt)
+        dx = torch.full((n, m), float("nan"), device=DEV, dtype=dt)
+        dk = torch.full((n,), float("nan"), device=DEV, dtype=dt)
+        rc = lib.vmf_log_prob_bwd(_lib.ptr(mub), pitch, _lib.ptr(kc), 1, _lib.ptr(xc), _lib.ptr(glc), _lib.ptr(dmu),
+                                  _lib.ptr(dx), _lib.ptr(dk), n, m, code, sp)
+        _lib.check(rc, "vmf_log_prob")
+        # only d x asked for: the slab is then filled once, not twice
+        dx2 = torch.full((n, m), float("nan"), device=DEV, dtype=dt)
+        rc = lib.vmf_log_prob_bwd(_lib.ptr(mub), pitch, _lib.ptr(kc), 1, _lib.ptr(xc), _lib.ptr(glc), None,
+                                  _lib.ptr(dx2), None, n, m, code, sp)
+        _lib.check(rc, "vmf_log_prob")
+        torch.cuda.synchronize()
+        assert torch.equal(dx, dx2)
+        return lp, dmu, dx, dk
+
+    want = run(torch.float64, m)
+    lane = run(torch.float32, m)
+    group = run(torch.float32, m + 1)
+    k32 = kappa.float().double()
+    for got in (lane, group):
+        # log p: log C_m ~ -kappa cancels most of kappa <mu, x>; an fp32 kappa and fp32 rows move each by ~kappa 1e-7
+        err = (got[0].double() - want[0]).abs() / (1.0 + want[0].abs() + 2e-3 * k32)
+        assert float(err.max()) < 1e-4, float(err.max())
+        for a, b in ((got[1], want[1]), (got[2], want[2])):
+            scale = (gl.abs() * k32)[:, None]
+            assert float(((a.double() - b).abs() / (scale + 1e-30)).max()) < 1e-6
+        assert float(((got[3].double() - want[3]).abs() / (gl.abs() + 1e-30)).max()) < 2e-6
+    # the two fp32 kernels differ only in the order of the sum <mu, x> (d mu and d x are products: the same bits)
+    assert torch.equal(lane[1], group[1]) and torch.equal(lane[2], group[2])
+    assert float((lane[0] - group[0]).abs().max()) <= 4e-7 * float((kappa.float().abs() + lane[0].abs()).max())
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.float64])
 def test_vmf3_log_prob_ref_tile_kernels_and_row_kernels_give_the_same_bits(dt):
     """CNN_experiment log_prob: aligned calls take whole tiles of 256 rows (plus a thread-per-row tail), views that start

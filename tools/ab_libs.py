@@ -19,7 +19,7 @@ ap.add_argument("--rows", type=int, default=1 << 24)
 ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--no-log-prob", action="store_true")
-ap.add_argument("--kernel", default="fwd", choices=["fwd", "bwd", "logprob", "s1fwd", "s1bwd"])
+ap.add_argument("--kernel", default="fwd", choices=["fwd", "bwd", "logprob", "logprobbwd", "s1fwd", "s1bwd"])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 n, m = a.rows, a.m
@@ -35,7 +35,7 @@ for spec in a.libs:
     h = C.CDLL(os.path.abspath(path))
     h.vmf_rsample_fwd.argtypes = _lib._PROTOS["vmf_rsample_fwd"]
     h.vmf_rsample_fwd.restype = C.c_int
-    for fn in ("vmf_rsample_bwd", "vmf_log_prob_fwd", "vmf_s1_projnormal_fwd", "vmf_s1_projnormal_bwd"):
+    for fn in ("vmf_rsample_bwd", "vmf_log_prob_fwd", "vmf_log_prob_bwd", "vmf_s1_projnormal_fwd", "vmf_s1_projnormal_bwd"):
         getattr(h, fn).argtypes = _lib._PROTOS[fn]
         getattr(h, fn).restype = C.c_int
     hs.append((name, h))
@@ -53,7 +53,7 @@ elif a.kernel != "fwd":
     assert rc == 0
     gz = torch.randn(n, m, device=dev)
     dmu = torch.empty_like(mu)
-    logp = torch.empty(n, device=dev)
+    logp = torch.randn(n, device=dev)
 
 
 def step(h, i):
@@ -70,6 +70,11 @@ def step(h, i):
     if a.kernel == "bwd":
         rc = h.vmf_rsample_bwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(w), _lib.ptr(omw), _lib.ptr(gz), None,
                                None, _lib.ptr(dmu), _lib.ptr(dk), n, m, 0, 0x5EED, 0, None, 0, _lib.VMF_F32, sp)
+        assert rc == 0, rc
+        return
+    if a.kernel == "logprobbwd":
+        rc = h.vmf_log_prob_bwd(_lib.ptr(mu), m, _lib.ptr(kappa), 1, _lib.ptr(z), _lib.ptr(logp), _lib.ptr(dmu), _lib.ptr(gz),
+                                _lib.ptr(dk), n, m, _lib.VMF_F32, sp)
         assert rc == 0, rc
         return
     if a.kernel == "logprob":

@@ -14,6 +14,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from _timing import timeit  # noqa: E402
+from medicalimageanalysis_amd import _lib  # noqa: E402
 from medicalimageanalysis_amd.sampler.ive import bessel_ratio, ive, log_ive  # noqa: E402
 from medicalimageanalysis_amd.sampler.von_mises_fisher import (VonMisesFisher, VonMisesFisher3D,  # noqa: E402
                                                                 VonMisesFisher3DLogProb)
@@ -47,6 +48,12 @@ for m, lg in ((10, 24), (64, 22)):
     d = VonMisesFisher(mu, kk)
     z = torch.nn.functional.normalize(torch.randn(nn, m, device=DEV, generator=g), dim=-1)
     row(f"VonMisesFisher(m={m}).log_prob, 2^{lg} fp32", timeit(lambda: d.log_prob(z)), nn * (2 * m + 2) * 4)
+    gl, dmu, dx, dk = torch.randn(nn, device=DEV, generator=g), torch.empty_like(mu), torch.empty_like(mu), torch.empty_like(kk)
+    sp = _lib.stream_ptr(DEV)
+    row(f"vmf_log_prob_bwd (d mu, d x, d kappa), m={m}, 2^{lg} fp32",
+        timeit(lambda: _lib.lib().vmf_log_prob_bwd(_lib.ptr(mu), m, _lib.ptr(kk), 1, _lib.ptr(z), _lib.ptr(gl), _lib.ptr(dmu),
+                                                   _lib.ptr(dx), _lib.ptr(dk), nn, m, 0, sp)), nn * (4 * m + 3) * 4)
+    del gl, dmu, dx, dk
     row(f"VonMisesFisher(m={m}).entropy, 2^{lg} fp32 (4 B in, 4 B out)", timeit(lambda: d.entropy()), nn * 8)
     row(f"VonMisesFisher(m={m}).kl_uniform, 2^{lg} fp32", timeit(lambda: d.kl_uniform()), nn * 8)
     del mu, kk, d, z
