@@ -578,13 +578,10 @@ __global__ __launch_bounds__(256) void vmf3_mean_kernel(const T* __restrict__ lo
                                                         BesselOrder o12) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    T r[3] = {loc[3 * i], loc[3 * i + 1], loc[3 * i + 2]};
-    T l[3], nn;
-    v3_normalise_loc<T>(r, l, &nn);
-    T a = (T)ive_eval(o32, (double)scale[i]);
-    T b = (T)ive_eval(o12, (double)scale[i]);
-    T A = a / b;  // sampler/von_mises_fisher.py:42
-    mean[3 * i] = l[0] * A; mean[3 * i + 1] = l[1] * A; mean[3 * i + 2] = l[2] * A;
+    const T r[3] = {loc[3 * i], loc[3 * i + 1], loc[3 * i + 2]};
+    T o[3];
+    v3_mean_row<T>(r, scale[i], o32, o12, o);  // sampler/von_mises_fisher.py:42
+    mean[3 * i] = o[0]; mean[3 * i + 1] = o[1]; mean[3 * i + 2] = o[2];
   }
 }
 
@@ -594,9 +591,17 @@ extern "C" int vmf3_mean(const void* loc, const void* scale, void* mean, int64_t
   VMF_REQUIRE(n >= 0, VMF_ERR_BAD_ARG, "n < 0");
   if (n == 0) return VMF_OK;
   VMF_REQUIRE(loc && scale && mean, VMF_ERR_BAD_ARG, "vmf3_mean: null pointer");
+  VMF_REQUIRE(dtype == VMF_F32 || dtype == VMF_F64, VMF_ERR_DTYPE, "dtype %d", dtype);
   BesselOrder o32 = make_bessel_order(1.5, 1), o12 = make_bessel_order(0.5, 1);
-  int grid = vmf_grid_for(n, 256);
-  VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(vmf3_mean_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                               (const T*)loc, (const T*)scale, (T*)mean, n, o32, o12));
+  // whole tiles of 256 rows when the pointers allow 16-byte accesses, the thread-per-row kernel for the rest
+  const int64_t done = vmf3_mean_tiles(loc, scale, mean, n, dtype, (hipStream_t)stream);
+  if (done < n) {
+    const int64_t es = dtype == VMF_F32 ? 4 : 8, rest = n - done;
+    int grid = vmf_grid_for(rest, 256);
+    VMF_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(vmf3_mean_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                                 (const T*)((const char*)loc + 3 * done * es),
+                                                 (const T*)((const char*)scale + done * es),
+                                                 (T*)((char*)mean + 3 * done * es), rest, o32, o12));
+  }
   return vmf_check_launch("vmf3_mean");
 }

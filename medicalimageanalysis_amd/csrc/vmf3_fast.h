@@ -26,6 +26,8 @@ int64_t vmf3_log_prob_ref_tiles(const void* loc, const void* scale, const void* 
                                 int dtype, hipStream_t stream);
 int64_t vmf3_log_prob_ref_bwd_tiles(const void* loc, const void* scale, const void* x, const void* gl, void* dloc,
                                     void* dscale, void* dx, int64_t n, int dtype, hipStream_t stream);
+// sampler/von_mises_fisher.py:42 (the mean direction) likewise
+int64_t vmf3_mean_tiles(const void* loc, const void* scale, void* mean, int64_t n, int dtype, hipStream_t stream);
 
 // Noise of index i comes from ONE call, Philox(i, slot 0) = (x, y, z, w) -- u01 reads the upper 23 bits of a word, so
 // five uniforms fit into the four words without sharing a bit:

@@ -685,3 +685,39 @@ int64_t vmf3_log_prob_ref_bwd_tiles(const void* loc, const void* scale, const vo
                        (double*)dx, ntiles);
   return ntiles * V3_TILE_ROWS;
 }
+
+// ---- (4) the mean direction, whole tiles ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void vmf3_mean_tile_kernel(const T* __restrict__ loc, const T* __restrict__ scale,
+                                                             T* __restrict__ mean, int64_t ntiles, BesselOrder o32,
+                                                             BesselOrder o12) {
+  constexpr int U = v3_units<T>();
+  __shared__ u32x4 s_slab[4][64 * U];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t t = (int64_t)blockIdx.x * 4 + wave;
+  if (t >= ntiles) return;  // wave-uniform; no workgroup barrier
+  const int64_t row0 = t * V3_TILE_ROWS;
+  u32x4* const slab = s_slab[wave];
+  u32x4 fl[U];
+  T r[12], k[4], o[12];
+  tile_fetch<T>(loc + 3 * row0, lane, fl);
+  quad_load<T>(scale + row0, lane, k);
+  tile_deal_in<T>(slab, lane, fl, r);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v3_mean_row<T>(r + 3 * j, k[j], o32, o12, o + 3 * j);
+  tile_store<T>(mean + 3 * row0, slab, lane, o);
+}
+
+int64_t vmf3_mean_tiles(const void* loc, const void* scale, void* mean, int64_t n, int dtype, hipStream_t stream) {
+  if (!lp_tiles_ok(n, {loc, scale, mean})) return 0;
+  const int64_t ntiles = n / V3_TILE_ROWS;
+  const dim3 grid((unsigned)((ntiles + 3) / 4)), block(256);
+  const BesselOrder o32 = make_bessel_order(1.5, 1), o12 = make_bessel_order(0.5, 1);
+  if (dtype == VMF_F32)
+    hipLaunchKernelGGL(vmf3_mean_tile_kernel<float>, grid, block, 0, stream, (const float*)loc, (const float*)scale,
+                       (float*)mean, ntiles, o32, o12);
+  else
+    hipLaunchKernelGGL(vmf3_mean_tile_kernel<double>, grid, block, 0, stream, (const double*)loc, (const double*)scale,
+                       (double*)mean, ntiles, o32, o12);
+  return ntiles * V3_TILE_ROWS;
+}

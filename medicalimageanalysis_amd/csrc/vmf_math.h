@@ -325,6 +325,26 @@ VMF_HD void v3_log_prob_ref_bwd_row(const T r[3], T k, const T xv[3], T g, T dlo
   for (int c = 0; c < 3; ++c) dloc[c] = dl[c] / nden - r[c] * rdl / (nn * nden * nden);
 }
 
+// sampler/von_mises_fisher.py:42 on one row: loc * (ive(3/2, k) / ive(1/2, k)), each ive rounded to T as the reference's
+// two calls round theirs
+template <typename T>
+VMF_HD void v3_mean_row(const T r[3], T k, const BesselOrder& o32, const BesselOrder& o12, T out[3]) {
+#pragma clang fp contract(off)
+  T l[3], nn;
+  v3_normalise_loc_fixed<T>(r, l, &nn);
+  double i12, i32;
+  const double kd = (double)k;
+  if (kd > 0.0 && kd < 1.0e300) {
+    ive_half_pair(kd, &i12, &i32);
+  } else {  // zero, negative, infinite, NaN: what the two calls return there
+    i32 = ive_eval(o32, kd);
+    i12 = ive_eval(o12, kd);
+  }
+  const T a = (T)i32, b = (T)i12;
+  const T A = a / b;
+  out[0] = l[0] * A; out[1] = l[1] * A; out[2] = l[2] * A;
+}
+
 // Unrolled on purpose (unlike the double-precision sums): single-precision coefficients are free 32-bit literals of
 // the fma, so a term costs two instructions instead of a scalar load and the loop bookkeeping.
 template <int n>

@@ -37,6 +37,9 @@ void hc_ratio_tab(double v, const double* z, double* out, int64_t n) {
   const IveTab t1 = make_ive_tab(make_bessel_order(v, 0)), t0 = make_ive_tab(make_bessel_order(v - 1.0, 0));
   for (int64_t i = 0; i < n; ++i) out[i] = bessel_ratio_tab(t1, t0, v, lg1, lg0, z[i]);
 }
+void hc_ive_half_pair(const double* z, double* i12, double* i32, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) ive_half_pair(z[i], &i12[i], &i32[i]);
+}
 void hc_log_norm_tab(int m, const double* k, double* out, double* a_out, int64_t n) {
   const VmfDim d = make_vmf_dim(m);
   const VmfDimTab t = make_vmf_dim_tab(d);

@@ -1652,6 +1652,39 @@ def test_vmf3_log_prob_ref_tile_kernels_and_row_kernels_give_the_same_bits(dt):
     assert float(err.max()) < tol, float(err.max())
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_vmf3_mean_tile_kernel_and_row_kernel_give_the_same_bits(dt):
+    """sampler/von_mises_fisher.py:42: aligned calls take whole tiles of 256 rows (plus a thread-per-row tail), a call
+    whose pointers start one element into their buffers the thread-per-row kernel throughout: same bits, and both equal
+    to loc (coth k - 1/k) evaluated in double precision"""
+    lib, sp = _lib.lib(), _lib.stream_ptr(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(13)
+    n = 256 * 7 + 131
+    loc = torch.randn(n, 3, device=DEV, generator=gen, dtype=dt)
+    k = torch.exp(torch.rand(n, device=DEV, generator=gen, dtype=dt) * 14 - 5)
+    k[:4] = torch.tensor([1e-3, 1.0, 0.99999, 500.0], device=DEV, dtype=dt)
+
+    def off(t):
+        buf = torch.empty(t.numel() + 1, device=DEV, dtype=dt)
+        v = buf[1:].view(t.shape)
+        v.copy_(t)
+        return v
+
+    def run(loc_, k_, out):
+        _lib.check(lib.vmf3_mean(_lib.ptr(loc_), _lib.ptr(k_), _lib.ptr(out), n, _lib.dtype_code(loc_), sp), "vmf3_mean")
+        return out.clone()
+
+    aligned = run(loc, k, torch.full((n, 3), float("nan"), device=DEV, dtype=dt))
+    rows = run(off(loc), off(k), off(torch.full((n, 3), float("nan"), device=DEV, dtype=dt)))
+    assert torch.equal(aligned, rows)
+    k64 = k.double()
+    A = 1.0 / torch.tanh(k64) - 1.0 / k64
+    A = torch.where(k64 < 1e-2, k64 / 3 - k64 ** 3 / 45, A)
+    ref = loc.double() / (loc.double().norm(dim=-1, keepdim=True) + 1e-5) * A[:, None]
+    tol = 1e-12 if dt == torch.float64 else 3e-7
+    assert float((aligned.double() - ref).abs().max()) < tol, float((aligned.double() - ref).abs().max())
+
+
 def test_gradients_reach_kappa_through_lognorm_and_mean():
     """CNN_experiment/von_mises_fisher.py:97-108 is differentiable in kappa, and so is the general-m mean A_m(kappa) mu"""
     k = (torch.rand(50, device=DEV, dtype=torch.float64) * 30 + 0.5).requires_grad_()

@@ -98,6 +98,16 @@ def test_device_table_driven_log_ive_ratio_lognorm_match_oracle(hc, oracle):
         np.testing.assert_allclose(a, oracle.bessel_ratio(0.5 * m, k), rtol=2e-10, err_msg=f"A m={m}")
 
 
+def test_device_half_integer_pair_matches_oracle_ive(hc, oracle):
+    """ive(1/2, x) and ive(3/2, x) evaluated together (the mean direction of the m = 3 distribution): the closed forms
+    above x = 1, ten series terms below, against the oracle's ive on a grid across the switch"""
+    x = np.concatenate([np.logspace(-12, 2.8, 1481), np.linspace(0.9, 1.1, 201), [1.0, np.nextafter(1.0, 0.0)]])
+    a, b = np.empty_like(x), np.empty_like(x)
+    hc.hc_ive_half_pair(_p(x), _p(a), _p(b), C.c_int64(x.size))
+    np.testing.assert_allclose(a, oracle.ive(0.5, x), rtol=1e-14)
+    np.testing.assert_allclose(b, oracle.ive(1.5, x), rtol=1e-14)
+
+
 def test_device_single_precision_log_normaliser(hc, oracle):
     """the fp32 log C_m(kappa) used for fp32 log_prob outputs: within fp32 rounding of the double oracle"""
     lib = oracle.lib()
