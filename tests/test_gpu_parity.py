@@ -2292,6 +2292,17 @@ def test_randomised_layouts_widths_and_offsets_against_the_oracle():
     assert out["worst"]["z"] < 2e-5 and out["worst"]["layout"] < 2e-6, out
 
 
+def test_randomised_widths_layouts_and_absent_outputs_of_log_prob_against_the_oracle():
+    """a short run of tests/fuzz_log_prob.py: widths 2..300, row counts around the tile sizes, padded rows, misaligned
+    bases, shared mu / kappa, absent gradient outputs, both precisions (every case asserts inside the sweep)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_log_prob", os.path.join(os.path.dirname(__file__), "fuzz_log_prob.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.sweep(250, 31)
+    assert out["rows"] > 100000 and out["lp64"] < 1e-10 and out["lp32"] < 1e-4, out
+
+
 def test_randomised_broadcast_shapes_of_the_m3_sampler_against_the_torch_restatement():
     """a short run of tests/fuzz_vmf3.py: random loc / scale / sample shapes and operand views, draw and gradients
     against the reference's op sequence under autograd (every case asserts inside the sweep)"""
