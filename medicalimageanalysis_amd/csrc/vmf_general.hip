@@ -29,6 +29,27 @@
 #define VMF_WAVES 4
 #endif
 constexpr int WAVES = VMF_WAVES;
+// Waves per workgroup of the kernels that have no workgroup barrier (a one-wave workgroup gives its slot back the moment
+// it ends; a four-wave one when its slowest wave does).  The lane-group backward and the log_prob dot kernel take theirs
+// from the launch (blockDim).  Same-box A/Bs against four waves everywhere, fp32: backward of 2^24 rows of 8 / 16 / 64
+// floats with one wave -2.5 / -2.8 / -3.5 %, 2^22 x 128 -1.1 %, 2^21 x 512 +9 % (stays at four); log_prob backward (dot
+// kernel) 2^22 x 64 -4.1 %, 2^19 x 512 -1.7 %, its forward +3 % (stays at four); the lane-per-row log_prob kernels with
+// two waves: rows of 16 floats -4 % forward, -12 % backward, rows of 10 the same as with four; the lane-per-row
+// sampler backward measures the same with 1, 2 or 4.
+#ifdef VMF_BWD_WAVES
+static int bwd_waves(int, int) { return VMF_BWD_WAVES; }
+#else
+static int bwd_waves(int lpr, int kpasses) { return lpr * kpasses <= 32 ? 1 : WAVES; }
+#endif
+#ifdef VMF_LP_WAVES
+static int lp_waves(bool) { return VMF_LP_WAVES; }
+#else
+static int lp_waves(bool bwd) { return bwd ? 1 : WAVES; }
+#endif
+#ifndef VMF_LPR_WAVES
+#define VMF_LPR_WAVES 2
+#endif
+constexpr int RLB_WAVES = WAVES, LPR_WAVES = VMF_LPR_WAVES;
 // mu, grad_z and x are read once by the backward / log_prob kernels: non-temporal 128-bit loads (2^24 x 64 fp32:
 // backward 2.48 -> 2.38 ms, log_prob 1.58 -> 1.37 ms)
 #ifndef VMF_BWD_STREAM
@@ -1178,7 +1199,7 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_kernel(GenParams<T
   const int sub = lane % LPR, grp = lane / LPR;
   const int m = p.m;
   const int64_t n_steps = (p.n + RPI - 1) / RPI;
-  const int64_t wave_id = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // 1 to WAVES waves per block
   // a wave takes STEPS consecutive steps; the grid covers all of them (neighbouring waves, neighbouring memory)
   constexpr int STEPS = bwd_steps(LPR, P);
   const int64_t step_end = (wave_id + 1) * STEPS < n_steps ? (wave_id + 1) * STEPS : n_steps;
@@ -1378,17 +1399,17 @@ __global__ __launch_bounds__(256) void vmf_circle_bwd_kernel(GenParams<T> p) {
 // rows scalar, guarded element accesses and idle lanes (m = 10: 47 % of the HBM rate).  Same arithmetic as the kernel
 // above, sums taken in element order.
 template <int M>
-__global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_rowlane_kernel(GenParams<float> p) {
+__global__ __launch_bounds__(RLB_WAVES * 64) void vmf_rsample_bwd_rowlane_kernel(GenParams<float> p) {
   using T = float;
   constexpr int RL_TILE = rl_tile(M);
   constexpr int UNITS = RL_TILE * M / 4;
   constexpr int UPL = (UNITS + 63) / 64;
   constexpr int CHUNKS = (M + 3) / 4;
-  __shared__ __align__(16) T s_rows[WAVES][RL_TILE * M];
+  __shared__ __align__(16) T s_rows[RLB_WAVES][RL_TILE * M];
   const PhiloxKey key = philox_resolve(p.ka);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   T* const srow = s_rows[wave];
-  const int64_t tile0 = ((int64_t)blockIdx.x * WAVES + wave) * RL_TILE;  // wave-uniform
+  const int64_t tile0 = ((int64_t)blockIdx.x * RLB_WAVES + wave) * RL_TILE;  // wave-uniform
   const int64_t left = p.n - tile0;
   if (left <= 0) return;  // the kernel has no workgroup barrier
   const int ntile = left < RL_TILE ? (int)left : RL_TILE;
@@ -1555,7 +1576,7 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_rsample_bwd_rowlane_kernel(Gen
 
 static void launch_bwd_rowlane(const GenParams<float>& p, hipStream_t s) {
   const int64_t tiles = (p.n + rl_tile(p.m) - 1) / rl_tile(p.m);
-  const dim3 grid((unsigned)((tiles + WAVES - 1) / WAVES)), block(WAVES * 64);
+  const dim3 grid((unsigned)((tiles + RLB_WAVES - 1) / RLB_WAVES)), block(RLB_WAVES * 64);
   switch (p.m) {
 #define VMF_RL(MM) case MM: hipLaunchKernelGGL((vmf_rsample_bwd_rowlane_kernel<MM>), grid, block, 0, s, p); break
     VMF_RL(3); VMF_RL(5); VMF_RL(6); VMF_RL(7); VMF_RL(9); VMF_RL(10); VMF_RL(11); VMF_RL(12); VMF_RL(13); VMF_RL(14);
@@ -1631,10 +1652,10 @@ static void launch_fwd(const FwdParams<T>& p, int grid, hipStream_t s) {
 }
 
 template <typename T, bool VEC>
-static void launch_bwd(const GenParams<T>& p, int grid, hipStream_t s) {
+static void launch_bwd(const GenParams<T>& p, int grid, int block_waves, hipStream_t s) {
   const int chunks = (p.m + 3) / 4;
 #define VMF_CALL(L, PP) \
-  hipLaunchKernelGGL((vmf_rsample_bwd_kernel<T, L, PP, VEC>), dim3(grid), dim3(WAVES * 64), 0, s, p)
+  hipLaunchKernelGGL((vmf_rsample_bwd_kernel<T, L, PP, VEC>), dim3(grid), dim3(block_waves * 64), 0, s, p)
   VMF_SHAPE_SWITCH(chunks, VMF_CALL);
 #undef VMF_CALL
 }
@@ -1767,7 +1788,8 @@ static int rsample_bwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   const int64_t steps = (n + (64 / lpr) - 1) / (64 / lpr);
   const int spw = bwd_steps(lpr, kpasses);
   const int64_t waves = (steps + spw - 1) / spw;
-  int64_t gb = (waves + WAVES - 1) / WAVES;
+  const int bw = bwd_waves(lpr, kpasses);
+  int64_t gb = (waves + bw - 1) / bw;
   VMF_REQUIRE(gb <= 0x7fffffff, VMF_ERR_UNSUPPORTED, "n=%lld rows need more than 2^31 workgroups", (long long)n);
   const int grid = (int)(gb < 1 ? 1 : gb);
   // dense circles with the regenerated sign: a thread per global pair of rows
@@ -1783,15 +1805,15 @@ static int rsample_bwd_t(const void* mu, int64_t mu_stride, const void* kappa, i
   if constexpr (sizeof(T) == 4) {
     // narrow rows of a width that is not a multiple of four, regenerated noise: one lane per row whatever the layout
     if (rowlane_bwd_ok(m) && !gauss) {
-      VMF_REQUIRE((n + rl_tile(m) - 1) / rl_tile(m) / WAVES < 0x7fffffff, VMF_ERR_UNSUPPORTED,
+      VMF_REQUIRE((n + rl_tile(m) - 1) / rl_tile(m) / RLB_WAVES < 0x7fffffff, VMF_ERR_UNSUPPORTED,
                   "n=%lld rows need more than 2^31 workgroups", (long long)n);
       p.dense16 = mu_stride == m && aligned16(mu) && aligned16(gz) && aligned16(dmu);
       launch_bwd_rowlane(p, s);
       return VMF_OK;
     }
   }
-  if (vec) launch_bwd<T, true>(p, grid, s);
-  else launch_bwd<T, false>(p, grid, s);
+  if (vec) launch_bwd<T, true>(p, grid, bw, s);
+  else launch_bwd<T, false>(p, grid, bw, s);
   return VMF_OK;
 }
 
@@ -1850,7 +1872,7 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_log_prob_dot_kernel(LogProbPar
   const int sub = lane % LPR, grp = lane / LPR;
   const int m = p.m;
   const int64_t n_steps = (p.n + RPI - 1) / RPI;
-  const int64_t wave_id = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // 1 to WAVES waves per block
   constexpr int LP_STEPS = lp_steps(BWD, LPR);
   const int64_t step_end = (wave_id + 1) * LP_STEPS < n_steps ? (wave_id + 1) * LP_STEPS : n_steps;
   for (int64_t step = wave_id * LP_STEPS; step < step_end; ++step) {  // wave-uniform
@@ -1894,7 +1916,7 @@ template <typename T, bool VEC, bool BWD>
 static void launch_log_prob(const LogProbParams<T>& p, int grid, hipStream_t s) {
   const int chunks = (p.m + 3) / 4;
 #define VMF_CALL(L, PP) \
-  hipLaunchKernelGGL((vmf_log_prob_dot_kernel<T, L, PP, VEC, BWD>), dim3(grid), dim3(WAVES * 64), 0, s, p)
+  hipLaunchKernelGGL((vmf_log_prob_dot_kernel<T, L, PP, VEC, BWD>), dim3(grid), dim3(lp_waves(BWD) * 64), 0, s, p)
   VMF_SHAPE_SWITCH(chunks, VMF_CALL);
 #undef VMF_CALL
 }
@@ -1910,7 +1932,7 @@ static void launch_log_prob(const LogProbParams<T>& p, int grid, hipStream_t s) 
 #define VMF_LPR_FUSE_A 1
 #endif
 template <int M, bool BWD>
-__global__ __launch_bounds__(WAVES * 64) void vmf_log_prob_rowlane_kernel(LogProbParams<float> p, float lc_v, float lc_lg,
+__global__ __launch_bounds__(LPR_WAVES * 64) void vmf_log_prob_rowlane_kernel(LogProbParams<float> p, float lc_v, float lc_lg,
                                                                           float lc_c0, VmfDim dim, VmfDimTab tab) {
   using T = float;
   constexpr int RL_TILE = rl_tile(M);
@@ -1921,11 +1943,11 @@ __global__ __launch_bounds__(WAVES * 64) void vmf_log_prob_rowlane_kernel(LogPro
   // start 8, 4 or 8 to a bank group, so those are kept 16 bytes apart (a pitch of an odd number of 16-byte units)
   constexpr int PITCH = M % 8 == 0 ? M + 4 : M;
   constexpr int UPR = M / 4;  // (used only when M % 8 == 0)
-  __shared__ __align__(16) T s_rows[WAVES][RL_TILE * PITCH];
+  __shared__ __align__(16) T s_rows[LPR_WAVES][RL_TILE * PITCH];
   auto unit_at = [](int q) { return M % 8 == 0 ? q + q / UPR : q; };
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   T* const srow = s_rows[wave];
-  const int64_t tile0 = ((int64_t)blockIdx.x * WAVES + wave) * RL_TILE;  // wave-uniform
+  const int64_t tile0 = ((int64_t)blockIdx.x * LPR_WAVES + wave) * RL_TILE;  // wave-uniform
   const int64_t left = p.n - tile0;
   if (left <= 0) return;  // the kernel has no workgroup barrier
   const int ntile = left < RL_TILE ? (int)left : RL_TILE;
@@ -2070,7 +2092,7 @@ static bool log_prob_rowlane_ok(int m) { return m >= 3 && m <= 32; }
 template <bool BWD>
 static void launch_log_prob_rowlane(const LogProbParams<float>& p, const VmfDim& dim, hipStream_t s) {
   const int64_t tiles = (p.n + rl_tile(p.m) - 1) / rl_tile(p.m);
-  const dim3 grid((unsigned)((tiles + WAVES - 1) / WAVES)), block(WAVES * 64);
+  const dim3 grid((unsigned)((tiles + LPR_WAVES - 1) / LPR_WAVES)), block(LPR_WAVES * 64);
   const float v = (float)dim.v, lg = (float)dim.lg_v1, c0 = (float)dim.half_m_log2pi;
   const VmfDimTab tab = BWD ? make_vmf_dim_tab(dim) : VmfDimTab{};
   switch (p.m) {
@@ -2099,7 +2121,7 @@ static int log_prob_t(const void* mu, int64_t mu_stride, const void* kappa, int6
     rowlane = log_prob_rowlane_ok(m) && mu_stride == m && aligned16(mu) && aligned16(x) && (!dmu || aligned16(dmu)) &&
               (!dx || aligned16(dx));
     if (rowlane)
-      VMF_REQUIRE((n + rl_tile(m) - 1) / rl_tile(m) / WAVES < 0x7fffffff, VMF_ERR_UNSUPPORTED,
+      VMF_REQUIRE((n + rl_tile(m) - 1) / rl_tile(m) / LPR_WAVES < 0x7fffffff, VMF_ERR_UNSUPPORTED,
                   "n=%lld rows need more than 2^31 workgroups", (long long)n);
   }
   if (rowterm && !(rowlane && (!BWD || VMF_LPR_FUSE_A)))
@@ -2118,7 +2140,7 @@ static int log_prob_t(const void* mu, int64_t mu_stride, const void* kappa, int6
   pick_shape(chunks, &lpr, &kpasses);
   const int64_t steps = (n + (64 / lpr) - 1) / (64 / lpr);
   const int64_t waves = (steps + lp_steps(BWD, lpr) - 1) / lp_steps(BWD, lpr);
-  int64_t gb = (waves + WAVES - 1) / WAVES;
+  int64_t gb = (waves + lp_waves(BWD) - 1) / lp_waves(BWD);
   VMF_REQUIRE(gb <= 0x7fffffff, VMF_ERR_UNSUPPORTED, "n=%lld rows need more than 2^31 workgroups", (long long)n);
   const int grid = (int)(gb < 1 ? 1 : gb);
   if (vec) launch_log_prob<T, true, BWD>(p, grid, s);
