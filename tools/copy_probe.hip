@@ -63,6 +63,54 @@ __global__ __launch_bounds__(WAVES * 64) void copy_tile(const f32x4* __restrict_
     if (t0 + 64 * u < n4) st<SM>(out + t0 + 64 * u, v[u]);
 }
 
+
+// The sampler's software pipeline without its arithmetic: a wave owns 32 KiB = 32 steps of 1 KiB, D loads in flight
+// (issued from inline asm, waits placed by hand: the memory counter retires loads and stores in issue order), one store
+// per step.  OLD = the wait the sampler uses today (D = 1: vmcnt(0) between a step's arithmetic and its store, so the
+// previous step's store is waited for as well); otherwise the wait sits at the top of the step and names the number of
+// younger operations: min(t, D) stores + min(D - 1, 31 - t) loads.  FILL dependent multiply-adds per step and PRE before
+// the first step stand in for the composition and the rejection phase.
+__device__ __forceinline__ void issue(f32x4& dst, const f32x4* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void wait_n(f32x4& dst, int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" : "+v"(dst) : : "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" : "+v"(dst) : : "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" : "+v"(dst) : : "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" : "+v"(dst) : : "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" : "+v"(dst) : : "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" : "+v"(dst) : : "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" : "+v"(dst) : : "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(7)" : "+v"(dst) : : "memory"); break;
+  }
+}
+template <int D, int FILL, int PRE, bool OLD>
+__global__ __launch_bounds__(256, 8) void copy_stream(const f32x4* __restrict__ in, f32x4* __restrict__ out, float a, float b) {
+  constexpr int STEPS = 32;
+  const uint32_t blk = xcd_block(blockIdx.x, gridDim.x);
+  const size_t t0 = ((size_t)blk * 4 + (threadIdx.x >> 6)) * (size_t)(64 * STEPS) + (threadIdx.x & 63);
+  f32x4 cur[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue(cur[d], in + t0 + 64 * d);
+  float acc = a;
+  for (int i = 0; i < PRE; ++i) acc = __builtin_fmaf(acc, a, b);
+  if (OLD) wait_n(cur[0], 0);
+#pragma unroll
+  for (int t = 0; t < STEPS; ++t) {
+    if (!OLD) wait_n(cur[t % D], (t < D ? t : D) + (D - 1 < STEPS - 1 - t ? D - 1 : STEPS - 1 - t));
+    f32x4 v = cur[t % D];
+    if (t + D < STEPS) issue(cur[t % D], in + t0 + 64 * (t + D));
+    if (t == 0) v.x += acc * b;
+    for (int i = 0; i < FILL / 4; ++i) {
+      v.x = __builtin_fmaf(v.x, a, b); v.y = __builtin_fmaf(v.y, a, b);
+      v.z = __builtin_fmaf(v.z, a, b); v.w = __builtin_fmaf(v.w, a, b);
+    }
+    if (OLD && t + 1 < STEPS) wait_n(cur[0], 0);
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" : : "v"(out + t0 + 64 * t), "v"(v) : "memory");
+  }
+}
+
 struct Result {
   const char* name;
   double best, med;
@@ -99,6 +147,27 @@ int main() {
   hipMemset(in, 1, bytes);
   hipMemset(out, 0, bytes);
   hipDeviceSynchronize();
+#define STREAM(D, FILL, PRE, OLD)                                                                          \
+  timeit("stream D" #D " fill " #FILL " pre " #PRE " old-wait " #OLD, [&] {                                  \
+    hipLaunchKernelGGL((copy_stream<D, FILL, PRE, OLD>), dim3((unsigned)(n4 / (64 * 32) / 4)), dim3(256), 0, 0, in, out, \
+                       1.0f, 0.0f);                                                                          \
+  }, bytes)
+  if (getenv("PROBE_STREAM")) {
+    STREAM(1, 0, 0, true);
+    STREAM(1, 0, 0, false);
+    STREAM(2, 0, 0, false);
+    STREAM(3, 0, 0, false);
+    STREAM(4, 0, 0, false);
+    STREAM(1, 128, 700, true);
+    STREAM(1, 128, 700, false);
+    STREAM(2, 128, 700, false);
+    STREAM(3, 128, 700, false);
+    STREAM(4, 128, 700, false);
+    STREAM(1, 256, 1400, true);
+    STREAM(2, 256, 1400, false);
+    STREAM(4, 256, 1400, false);
+    return 0;
+  }
   timeit("hipMemcpyAsync device-to-device", [&] { hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, 0); }, bytes);
 #define STRIDE(LM, SM, U, BLOCKS)                                                                        \
   timeit("stride ld" #LM " st" #SM " U" #U " blocks " #BLOCKS,                                             \
