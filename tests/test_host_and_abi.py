@@ -493,25 +493,51 @@ def test_streaming_kernels_keep_their_hands_off_registers_with_a_load_in_flight(
         for name in names:
             dis = subprocess.run([objdump, "-d", f"--disassemble-symbols={name}", str(f)], check=True, capture_output=True,
                                  text=True, timeout=300).stdout
-            ins = [ln.split("//")[0].strip() for ln in dis.splitlines() if re.match(r"^\s+[a-z_0-9]+ ", ln)]
+            # (text, address, branch target address or None) per instruction; the scan follows the control flow -- an
+            # unconditional branch is taken, a conditional one is followed both ways -- so that a block the code jumps
+            # over (the copies of the "no further rows" path right behind a load) is not mistaken for what runs next
+            ins = []
+            for ln in dis.splitlines():
+                mm = re.match(r"^\s+([a-z_0-9]+ .*?)\s*//\s*([0-9A-Fa-f]+):[^<]*(?:<[^>]*\+0x([0-9a-fA-F]+)>)?\s*$", ln)
+                if mm:
+                    ins.append((mm.group(1).strip(), int(mm.group(2), 16), mm.group(3)))
+            assert ins, name
+            base = ins[0][1]
+            index_of = {addr: i for i, (_, addr, _) in enumerate(ins)}
             kernels += 1
-            in_flight = {}   # destination register -> index of the load that owns it
-            for i, text in enumerate(ins):
-                op, _, operands = text.partition(" ")
-                if op == "global_load_dwordx4" and operands.rstrip().endswith(" nt"):
-                    dst = _vregs(operands.split(",")[0])
-                    assert not (dst & set(in_flight)), (name, i, text)
-                    # the address registers are read by this very instruction: they must not be in flight either
-                    assert not (_vregs(",".join(operands.split(",")[1:])) & set(in_flight)), (name, i, text)
-                    for r in dst:
-                        in_flight[r] = i
-                    prefetches += 1
-                    continue
-                if op == "s_waitcnt" and "vmcnt(0)" in operands:
-                    in_flight.clear()
-                    continue
-                if in_flight and op.startswith(("v_", "global_", "ds_", "buffer_", "scratch_", "flat_")):
-                    touched = _vregs(operands) & set(in_flight)
-                    assert not touched, (name, i, text, sorted(touched), ins[max(0, i - 3):i + 1])
-            assert not in_flight, (name, "a prefetch is never waited for")
+            loads_seen = set()
+            seen = set()
+            stack = [(0, frozenset())]
+            while stack:
+                i, in_flight = stack.pop()
+                while i < len(ins):
+                    if (i, in_flight) in seen:
+                        break
+                    seen.add((i, in_flight))
+                    text, _, target = ins[i]
+                    op, _, operands = text.partition(" ")
+                    if op == "global_load_dwordx4" and operands.rstrip().endswith(" nt"):
+                        dst = _vregs(operands.split(",")[0])
+                        assert not (dst & in_flight), (name, i, text)
+                        # the address registers are read by this very instruction: they must not be in flight either
+                        assert not (_vregs(",".join(operands.split(",")[1:])) & in_flight), (name, i, text)
+                        in_flight = in_flight | dst
+                        loads_seen.add(i)
+                    elif op == "s_waitcnt" and "vmcnt(0)" in operands:
+                        in_flight = frozenset()
+                    elif in_flight and op.startswith(("v_", "global_", "ds_", "buffer_", "scratch_", "flat_")):
+                        touched = _vregs(operands) & in_flight
+                        assert not touched, (name, i, text, sorted(touched), [t for t, _, _ in ins[max(0, i - 3):i + 1]])
+                    if op == "s_endpgm":
+                        assert not in_flight, (name, "a prefetch is never waited for")
+                        break
+                    if op == "s_branch" or op.startswith("s_cbranch"):
+                        assert target is not None, (name, i, text)
+                        j = index_of[base + int(target, 16)]
+                        if op == "s_branch":
+                            i = j
+                            continue
+                        stack.append((j, in_flight))
+                    i += 1
+            prefetches += len(loads_seen)
     assert kernels >= 10 and prefetches >= 2 * kernels, (kernels, prefetches)
