@@ -802,7 +802,10 @@ def test_general_rsample_predrawn_accept_index_bit_exact(oracle, tag, m, n):
 
 @pytest.mark.parametrize("tag", ["f64", "f32"])
 @pytest.mark.parametrize("m,n", [(64, 70000), (512, 3000), (10, 4097), (3, 999), (2, 50001), (4, 3000), (12, 1500),
-                                 (17, 777), (22, 4099), (31, 1000), (96, 3000), (70, 1001), (768, 300)])
+                                 (17, 777), (22, 4099), (31, 1000), (96, 3000), (70, 1001), (768, 300),
+                                 # the other one-pass streaming widths: their full tiles and their last, ragged tile run
+                                 # two copies of the streaming loop, and the shard below must not see which
+                                 (32, 9001), (128, 5001), (256, 2500)])
 def test_general_rsample_philox_vs_oracle(oracle, tag, m, n):
     gen = np.random.default_rng(200 + m)
     dt = np.float64 if tag == "f64" else np.float32
