@@ -69,11 +69,11 @@ def record_margin(name, err, tol):
 GRAD_RT32 = 1e-4  # fp32 gradients: relative to the element plus the same fraction of the tensor's largest element
 
 
-def close_grad(got, ref, tag, name, rt64=1e-9):
+def close_grad(got, ref, tag, name, rt64=1e-9, rt32=None):
     """gradient tensors: |got - ref| <= rt (|ref| + max |ref|), rt = 1e-4 in fp32 (measured: 3e-6 of it, see the recorded margins);
     the largest error and the share of the allowance it used are recorded like the draws' (MARGINS)"""
     got64, ref64 = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
-    rt = rt64 if tag == "f64" else GRAD_RT32
+    rt = rt64 if tag == "f64" else (GRAD_RT32 if rt32 is None else rt32)
     tol = rt * (np.abs(ref64) + np.abs(ref64).max())
     err = np.abs(got64 - ref64)
     test = os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0].split("[")[0]
@@ -614,8 +614,8 @@ def test_vmf3_broadcast_backward_is_reproducible_and_matches_atomics(monkeypatch
     we = w.unsqueeze(-1)
     z = we * l + torch.sqrt(torch.clamp(1 - we ** 2, 1e-10, 1.0)) * v
     (z * c.double()).sum().backward()
-    np.testing.assert_allclose(N(a1), N(loc64.grad), rtol=2e-3, atol=2e-3)
-    np.testing.assert_allclose(N(b1), N(kap64.grad), rtol=2e-3, atol=2e-4)
+    close_grad(N(a1), N(loc64.grad), "f32", "outer_dloc_vs_autograd", rt32=5e-4)
+    close_grad(N(b1), N(kap64.grad), "f32", "outer_dscale_vs_autograd", rt32=5e-4)
     # sample shape (5,) with an elementwise scale (B,): loc and scale gradients sum over the sample dimension
     k1 = (torch.rand(B, device=DEV, generator=gen, dtype=torch.float64) * 50 + 1).requires_grad_()
     l1 = torch.randn(B, 3, device=DEV, generator=gen, dtype=torch.float64).requires_grad_()
@@ -1101,8 +1101,7 @@ def test_spherical_vae_train_step_batch128():
     np.testing.assert_allclose(N(z), N(z_ref), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(float(loss.detach()), float(loss_ref.detach()), rtol=1e-5)
     for (name, a), (_, b) in zip(model.named_parameters(), ref.named_parameters()):
-        scale = float(b.grad.abs().max()) + 1e-12
-        np.testing.assert_allclose(N(a.grad), N(b.grad), rtol=2e-3, atol=2e-3 * scale, err_msg=name)
+        close_grad(N(a.grad), N(b.grad), "f32", name, rt32=5e-4)
     before = [p.detach().clone() for p in model.parameters()]
     opt.step()
     assert any(not torch.equal(a, b) for a, b in zip(before, model.parameters()))
